@@ -1,0 +1,140 @@
+/*
+ * bsrnn_hip.h -- C ABI of the MI355X-native BSRNN separation path (libbsrnn_hip.so).
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no torch / C++ types.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repo phhusson/SpeechSeparation).  Host bindings (ctypes, the LADSPA plugin,
+ * or a libtorch/pybind stub in the reference itself) bind exactly these symbols; see
+ * INTEGRATION.md for the reference-side stubs.
+ *
+ * Conventions
+ *   - all tensors are contiguous float32;
+ *   - "dev" pointers are device (HIP) pointers on the context's device, "host" pointers are
+ *     ordinary host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls enqueue work
+ *     and return without synchronising unless stated otherwise;
+ *   - return value 0 = success, otherwise a BSRNN_E* code; bsrnn_last_error() gives text;
+ *   - nothing here ever falls back to a CPU implementation.
+ *   - C = rows of dim 0 (utterance-channels), T / L = STFT frames, F2 = 2050 interleaved
+ *     re/im columns, K = number of bands including the zero-width band, H = 64.
+ */
+#ifndef BSRNN_HIP_H
+#define BSRNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSRNN_ABI_VERSION 1
+
+#define BSRNN_OK          0
+#define BSRNN_EARG        1   /* bad argument / shape */
+#define BSRNN_ESTATE      2   /* call out of order (e.g. compute before commit) */
+#define BSRNN_EHIP        3   /* HIP runtime error */
+#define BSRNN_EIO         4   /* weight file problem */
+#define BSRNN_ENOKEY      5   /* unknown parameter key */
+
+typedef struct bsrnn_ctx bsrnn_ctx;
+typedef struct bsrnn_stream bsrnn_stream;
+
+int         bsrnn_abi_version(void);
+const char* bsrnn_last_error(void);
+
+/* ---- construction -------------------------------------------------------------------
+ * Replaces `BSRNN()` (bsrnn.py:328-376).  `widths` are band widths in bins, in order,
+ * including the trailing zero-width band (generate_bandsplits()[0], bsrnn.py:247-326);
+ * sum(widths) must be 1025.  The band table is data: pass a different one for the
+ * 41-band variant.  `device` is the HIP device ordinal. */
+int  bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx** out);
+void bsrnn_destroy(bsrnn_ctx* ctx);
+int  bsrnn_n_bands(const bsrnn_ctx* ctx);
+int  bsrnn_device(const bsrnn_ctx* ctx);
+
+/* ---- parameters ---------------------------------------------------------------------
+ * Replaces `load_state_dict` (infer.py:19, infer-streaming.py:46): parameters are named
+ * by the reference's state_dict keys and given as host float32
+ * in torch layout (Linear weight [out,in]).  bsrnn_commit_params() folds/packs/uploads
+ * and must be called after the last bsrnn_set_param() and before any compute call. */
+int  bsrnn_param_count(const bsrnn_ctx* ctx);
+int  bsrnn_param_info(const bsrnn_ctx* ctx, int32_t index, const char** key,
+                      int64_t* dim0, int64_t* dim1, int32_t* ndim);
+int  bsrnn_set_param(bsrnn_ctx* ctx, const char* key, const float* host_data, int64_t numel);
+int  bsrnn_get_param(const bsrnn_ctx* ctx, const char* key, float* host_out, int64_t numel);
+int  bsrnn_commit_params(bsrnn_ctx* ctx);
+/* Flat weight file (speechseparation_amd/weights.py) -- replaces the ONNX file that
+ * speech-ladspa-onnx.cpp:73 opens.  Does set_param for every tensor, then commit. */
+int  bsrnn_load_weights_file(bsrnn_ctx* ctx, const char* path);
+
+/* ---- model entry points ---------------------------------------------------------------
+ * bsrnn_forward            = BSRNN.forward            (bsrnn.py:385-443)
+ *     x_dev [C, 2050, T] -> y_dev [C, 2050, T]   (y = x * mask; x is not modified)
+ * bsrnn_forward_recurrent  = BSRNN.forward_recurrent  (bsrnn.py:445-510)
+ *     x_dev [C, 2050], state_in_dev [4, 2, C*K, 64] -> y_dev [C, 2050], state_out_dev (same
+ *     shape; may alias state_in_dev).  State slabs: 0/1 = h/c of lstms.1, 2/3 = h/c of
+ *     lstms.3; dim 1 = LSTM layer; dim 2 = c*K + k.
+ * bsrnn_forward_chunk      = L consecutive forward_recurrent steps in one call (BASELINE.json
+ *     config 3): x_dev [C, 2050, L], state carried causally; L = 1 equals forward_recurrent.
+ * mask_dev (optional, may be NULL): receives the mask [C, 2050, T] (bsrnn.py:425-432). */
+int  bsrnn_forward(bsrnn_ctx* ctx, const float* x_dev, float* y_dev, float* mask_dev,
+                   int32_t C, int32_t T, void* stream);
+int  bsrnn_forward_recurrent(bsrnn_ctx* ctx, const float* x_dev, const float* state_in_dev,
+                             float* y_dev, float* state_out_dev, int32_t C, void* stream);
+int  bsrnn_forward_chunk(bsrnn_ctx* ctx, const float* x_dev, const float* state_in_dev,
+                         float* y_dev, float* state_out_dev, int32_t C, int32_t L, void* stream);
+
+/* `self.lstms(z)` alone (bsrnn.py:352-356, :417): z_dev [C, T, K, 64] -> z_out_dev.  state
+ * pointers may be NULL (zero initial state, final state discarded). */
+int  bsrnn_dual_path(bsrnn_ctx* ctx, const float* z_dev, float* z_out_dev,
+                     const float* state_in_dev, float* state_out_dev,
+                     int32_t C, int32_t T, void* stream);
+
+/* ---- the STFT sandwich of the callers --------------------------------------------------
+ * bsrnn_stft   = infer.py:29-33 (dup. m_dataset.py:187-190): wave_dev [R, n] ->
+ *                x_dev [R, 2050, T], T = 1 + n/1024; periodic Hann 2048, hop 1024,
+ *                center/reflect, onesided, re/im interleaved.  n must be > 1024.
+ * bsrnn_istft  = infer.py:35-37: y_dev [R, 2050, T] -> wave_out_dev [R, (T-1)*1024].
+ * bsrnn_separate = the whole sandwich fused on the device (frame-major internally, no
+ *                [C,2050,T] round trips): wave_dev [R, n] -> wave_out_dev [R, (T-1)*1024]. */
+int  bsrnn_stft(bsrnn_ctx* ctx, const float* wave_dev, float* x_dev, int32_t R, int64_t n, void* stream);
+int  bsrnn_istft(bsrnn_ctx* ctx, const float* y_dev, float* wave_out_dev, int32_t R, int32_t T, void* stream);
+int  bsrnn_separate(bsrnn_ctx* ctx, const float* wave_dev, float* wave_out_dev, int32_t R, int64_t n, void* stream);
+
+/* ---- streaming (infer-streaming.py:84-147; speech-ladspa-onnx.cpp:171-267) -------------
+ * A bsrnn_stream owns, on the device, the sliding 2048-sample analysis buffer, the LSTM
+ * state [4,2,C*K,64] and the previous synthesis frame for C rows.
+ * bsrnn_stream_step: chunk_dev [C, 1024] -> out_dev [C, 1024] (delayed by one chunk):
+ *     rfft(buf*hann) -> forward_recurrent -> irfft -> 2-slot overlap-add / sum(window).
+ * bsrnn_stream_step_host: same with host buffers, synchronous (used by the LADSPA plugin);
+ *     `mix` applies the plugin's wet/dry control on the spectrum (speech-ladspa-onnx.cpp:
+ *     215-226): mix >= 0: mix*y + (1-mix)*x ; mix < 0: x + mix*y.  Use mix = 1 for
+ *     infer-streaming.py semantics. */
+int  bsrnn_stream_create(bsrnn_ctx* ctx, int32_t C, bsrnn_stream** out);
+void bsrnn_stream_destroy(bsrnn_stream* s);
+int  bsrnn_stream_reset(bsrnn_stream* s, void* stream);
+int  bsrnn_stream_step(bsrnn_stream* s, const float* chunk_dev, float* out_dev, float mix, void* stream);
+int  bsrnn_stream_step_host(bsrnn_stream* s, const float* chunk_host, float* out_host, float mix);
+int  bsrnn_stream_get_state(bsrnn_stream* s, float* state_host /* [4,2,C*K,64] */);
+
+/* ---- measurement support ---------------------------------------------------------------
+ * With profiling on, every stage of a compute call is bracketed by hipEvents on the call's
+ * stream; bsrnn_stage_times() synchronises on the last call and returns per-stage elapsed
+ * milliseconds (accumulated since the last reset) and launch counts.  Stage names:
+ * bsrnn_stage_name(i).  Used by bench.py for the live roofline figure. */
+int         bsrnn_set_profiling(bsrnn_ctx* ctx, int32_t on);
+int         bsrnn_stage_count(void);
+const char* bsrnn_stage_name(int32_t i);
+int         bsrnn_stage_times(bsrnn_ctx* ctx, double* ms_out, int64_t* launches_out, int32_t reset);
+
+/* ---- device memory helpers for hosts without a HIP binding (the plugin, C tests) -------- */
+int  bsrnn_dev_alloc(bsrnn_ctx* ctx, int64_t nbytes, void** out);
+int  bsrnn_dev_free(bsrnn_ctx* ctx, void* p);
+int  bsrnn_copy_h2d(bsrnn_ctx* ctx, void* dst_dev, const void* src_host, int64_t nbytes);
+int  bsrnn_copy_d2h(bsrnn_ctx* ctx, void* dst_host, const void* src_dev, int64_t nbytes);
+int  bsrnn_sync(bsrnn_ctx* ctx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSRNN_HIP_H */

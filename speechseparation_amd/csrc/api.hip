@@ -1,0 +1,910 @@
+// C ABI of libbsrnn_hip.so (include/bsrnn_hip.h): context, parameter intake by the reference's
+// state_dict key names, host-side folding/packing, workspace, and the launch sequence of
+// BSRNN.forward / forward_recurrent (bsrnn.py:385-510) and of the callers' STFT sandwich.
+// There is no CPU compute path here: every entry point either enqueues HIP kernels or fails.
+#include "../../include/bsrnn_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace bsrnn;
+
+// --------------------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(BSRNN_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// --------------------------------------------------------------------------- context
+namespace {
+
+struct Param {
+    std::string key;
+    int64_t d0 = 0, d1 = 0;
+    int ndim = 1;
+    std::vector<float> data;
+    bool set = false;
+    int64_t numel() const { return ndim == 2 ? d0 * d1 : d0; }
+};
+
+enum Slot { PRE0, PRE2, FC0, FC2, FC4, BACK0, BACK2, BACK4, POST0, POST2, BLK_FC0, BLK_FC1, BLK_FC2, BLK_FC3, NSLOT };
+
+enum Stage { ST_LAYOUT, ST_STFT, ST_BANDSPLIT, ST_BAND_LSTM, ST_BAND_FC, ST_TIME_LSTM, ST_TIME_FC, ST_MASK, ST_ISTFT, ST_STREAM_DSP, NSTAGE };
+const char* kStageNames[NSTAGE] = {"layout", "stft", "bandsplit_mlp", "band_lstm", "band_fc", "time_lstm", "time_fc",
+                                   "mask_mlp", "istft", "stream_dsp"};
+
+struct EvRec { hipEvent_t a, b; int stage; };
+
+}  // namespace
+
+struct bsrnn_ctx {
+    int device = 0;
+    std::vector<int> widths, off;   // bins per band, start bin
+    int K = 0;
+    std::vector<Param> params;
+    std::map<std::string, int> index;
+    bool committed = false;
+
+    // activation column layout
+    std::vector<int> aoff, poff;
+    int LDA = 0, LDP = 0;
+
+    // device-resident weights and tables
+    float* d_arena = nullptr;
+    GemmJob* d_jobs = nullptr;
+    int2* d_tiles = nullptr;
+    int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT];
+    const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
+    float* d_tables = nullptr;
+    FftTables tb;
+
+    // workspace (grow-only)
+    size_t cap_rows = 0;
+    float* d_ws = nullptr;
+    float *Xf, *Yf, *A1, *A2, *P, *Z0, *Z1, *HB0, *HB1, *H1, *frames;
+    size_t tap_rows = 0;
+    float* d_tap = nullptr;
+
+    // profiling
+    bool prof = false;
+    std::vector<EvRec> pool;
+    size_t pool_used = 0;
+    double acc_ms[NSTAGE];
+    int64_t acc_n[NSTAGE];
+    hipStream_t last_stream = nullptr;
+};
+
+struct bsrnn_stream {
+    bsrnn_ctx* ctx;
+    int C;
+    float *buf, *prev, *state, *X, *Y, *chunk, *out;
+};
+
+namespace {
+
+struct StageScope {   // brackets one stage of a call with events when profiling is on
+    bsrnn_ctx* c; hipStream_t s; EvRec* r = nullptr;
+    StageScope(bsrnn_ctx* c_, int stage, hipStream_t s_) : c(c_), s(s_)
+    {
+        if (c->prof && c->pool_used < c->pool.size()) {
+            r = &c->pool[c->pool_used++];
+            r->stage = stage;
+            (void)hipEventRecord(r->a, s);
+        }
+    }
+    ~StageScope() { if (r) (void)hipEventRecord(r->b, s); }
+};
+
+int add_param(bsrnn_ctx* c, const std::string& key, int64_t d0, int64_t d1, int ndim)
+{
+    Param p;
+    p.key = key; p.d0 = d0; p.d1 = d1; p.ndim = ndim;
+    c->index[key] = (int)c->params.size();
+    c->params.push_back(p);
+    return 0;
+}
+void add_linear(bsrnn_ctx* c, const std::string& prefix, int n_out, int n_in)
+{
+    add_param(c, prefix + ".weight", n_out, n_in, 2);
+    add_param(c, prefix + ".bias", n_out, 0, 1);
+}
+int imax(int a, int b) { return a > b ? a : b; }
+int round4(int a) { return (a + 3) & ~3; }
+
+// parameter inventory in the reference's state_dict order (bsrnn.py:329-376)
+void build_inventory(bsrnn_ctx* c)
+{
+    char b[128];
+    const int H = HID;
+    for (int i = 0; i < c->K; ++i) {
+        const int a = 2 * c->widths[i];
+        if (a > 0) {
+            snprintf(b, sizeof b, "bandFCs_pre.%d.0", i); add_linear(c, b, a, a);
+            snprintf(b, sizeof b, "bandFCs_pre.%d.2", i); add_linear(c, b, a, a);
+        } else { snprintf(b, sizeof b, "bandFCs_pre.%d.0.trainable_constant", i); add_param(c, b, 0, 0, 1); }
+    }
+    for (int i = 0; i < c->K; ++i) {
+        const int a = 2 * c->widths[i], m = imax(a, H);
+        if (a > 0) {
+            snprintf(b, sizeof b, "bandFCs.%d.0", i); add_linear(c, b, m, a);
+            snprintf(b, sizeof b, "bandFCs.%d.2", i); add_linear(c, b, H, m);
+            snprintf(b, sizeof b, "bandFCs.%d.4", i); add_linear(c, b, H, H);
+        } else { snprintf(b, sizeof b, "bandFCs.%d.0.trainable_constant", i); add_param(c, b, H, 0, 1); }
+    }
+    for (int j = 0; j < 4; ++j) {
+        const bool bidir = (j % 2 == 0);
+        snprintf(b, sizeof b, "lstms.%d.m.fc_in", j); add_linear(c, b, H, H);
+        for (int layer = 0; layer < 2; ++layer) {
+            const int n_in = layer == 0 ? H : (bidir ? 2 * H : H);
+            for (int d = 0; d < (bidir ? 2 : 1); ++d) {
+                const char* sfx = d ? "_reverse" : "";
+                snprintf(b, sizeof b, "lstms.%d.m.rnn.weight_ih_l%d%s", j, layer, sfx); add_param(c, b, 4 * H, n_in, 2);
+                snprintf(b, sizeof b, "lstms.%d.m.rnn.weight_hh_l%d%s", j, layer, sfx); add_param(c, b, 4 * H, H, 2);
+                snprintf(b, sizeof b, "lstms.%d.m.rnn.bias_ih_l%d%s", j, layer, sfx); add_param(c, b, 4 * H, 0, 1);
+                snprintf(b, sizeof b, "lstms.%d.m.rnn.bias_hh_l%d%s", j, layer, sfx); add_param(c, b, 4 * H, 0, 1);
+            }
+        }
+        snprintf(b, sizeof b, "lstms.%d.m.fc", j); add_linear(c, b, H, bidir ? 2 * H : H);
+    }
+    for (int i = 0; i < c->K; ++i) {
+        const int a = 2 * c->widths[i], pz = imax(a, 2 * H);
+        if (a > 0) {
+            snprintf(b, sizeof b, "bandFCs_back.%d.0", i); add_linear(c, b, 2 * H, H);
+            snprintf(b, sizeof b, "bandFCs_back.%d.2", i); add_linear(c, b, pz, 2 * H);
+            snprintf(b, sizeof b, "bandFCs_back.%d.4", i); add_linear(c, b, a, pz);
+        } else { snprintf(b, sizeof b, "bandFCs_back.%d.0.trainable_constant", i); add_param(c, b, 0, 0, 1); }
+    }
+    for (int i = 0; i < c->K; ++i) {
+        const int a = 2 * c->widths[i];
+        if (a > 0) {
+            snprintf(b, sizeof b, "bandFCs_back_post.%d.0", i); add_linear(c, b, a, a);
+            snprintf(b, sizeof b, "bandFCs_back_post.%d.2", i); add_linear(c, b, a, a);
+        } else { snprintf(b, sizeof b, "bandFCs_back_post.%d.0.trainable_constant", i); add_param(c, b, 0, 0, 1); }
+    }
+}
+
+const Param& P_(const bsrnn_ctx* c, const std::string& key) { return c->params[c->index.at(key)]; }
+
+// host-side arena builder (16-byte aligned segments)
+struct Arena {
+    std::vector<float> h;
+    size_t put(const float* p, size_t n)
+    {
+        size_t o = (h.size() + 3) & ~size_t(3);
+        h.resize(o + n);
+        if (n) memcpy(&h[o], p, n * sizeof(float));
+        return o;
+    }
+    size_t put(const std::vector<float>& v) { return put(v.data(), v.size()); }
+};
+
+// [W_ih (fc_in folded for layer 0) | W_hh] and the summed bias of one LSTM layer/direction
+void lstm_cat(const bsrnn_ctx* c, int j, int layer, const char* sfx, int n_in, std::vector<double>& wcat, std::vector<double>& bsum)
+{
+    char b[128];
+    const int H = HID, KT = n_in + H;
+    snprintf(b, sizeof b, "lstms.%d.m.rnn.weight_ih_l%d%s", j, layer, sfx); const Param& wih = P_(c, b);
+    snprintf(b, sizeof b, "lstms.%d.m.rnn.weight_hh_l%d%s", j, layer, sfx); const Param& whh = P_(c, b);
+    snprintf(b, sizeof b, "lstms.%d.m.rnn.bias_ih_l%d%s", j, layer, sfx); const Param& bih = P_(c, b);
+    snprintf(b, sizeof b, "lstms.%d.m.rnn.bias_hh_l%d%s", j, layer, sfx); const Param& bhh = P_(c, b);
+    wcat.assign((size_t)4 * H * KT, 0.0);
+    bsum.assign(4 * H, 0.0);
+    for (int r = 0; r < 4 * H; ++r) bsum[r] = (double)bih.data[r] + (double)bhh.data[r];
+    if (layer == 0) {
+        // fc_in folded: W' = W_ih W_in, b' += W_ih b_in   (bsrnn.py:82-83: rnn(fc_in(x)), no activation between)
+        snprintf(b, sizeof b, "lstms.%d.m.fc_in.weight", j); const Param& win = P_(c, b);
+        snprintf(b, sizeof b, "lstms.%d.m.fc_in.bias", j); const Param& bin = P_(c, b);
+        for (int r = 0; r < 4 * H; ++r) {
+            for (int k = 0; k < H; ++k) {
+                double s = 0;
+                for (int u = 0; u < H; ++u) s += (double)wih.data[(size_t)r * H + u] * (double)win.data[(size_t)u * H + k];
+                wcat[(size_t)r * KT + k] = s;
+            }
+            double sb = 0;
+            for (int u = 0; u < H; ++u) sb += (double)wih.data[(size_t)r * H + u] * (double)bin.data[u];
+            bsum[r] += sb;
+        }
+    } else {
+        for (int r = 0; r < 4 * H; ++r)
+            for (int k = 0; k < n_in; ++k) wcat[(size_t)r * KT + k] = wih.data[(size_t)r * n_in + k];
+    }
+    for (int r = 0; r < 4 * H; ++r)
+        for (int k = 0; k < H; ++k) wcat[(size_t)r * KT + n_in + k] = whh.data[(size_t)r * H + k];
+}
+
+int ensure_ws(bsrnn_ctx* c, size_t rows)
+{
+    if (rows <= c->cap_rows) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->d_ws) { HIP_TRY(hipFree(c->d_ws)); c->d_ws = nullptr; c->cap_rows = 0; }
+    const size_t KH = (size_t)c->K * HID;
+    auto seg = [](size_t n) { return (n + 63) & ~size_t(63); };
+    const size_t sizes[11] = {seg(rows * F2), seg(rows * F2), seg(rows * c->LDA), seg(rows * c->LDA), seg(rows * c->LDP),
+                              seg(rows * KH), seg(rows * KH), seg(rows * KH * 2), seg(rows * KH * 2), seg(rows * KH), seg(rows * NFFT)};
+    size_t total = 0;
+    for (size_t s : sizes) total += s;
+    HIP_TRY(hipMalloc((void**)&c->d_ws, total * sizeof(float)));
+    float* p = c->d_ws;
+    float** dst[11] = {&c->Xf, &c->Yf, &c->A1, &c->A2, &c->P, &c->Z0, &c->Z1, &c->HB0, &c->HB1, &c->H1, &c->frames};
+    for (int i = 0; i < 11; ++i) { *dst[i] = p; p += sizes[i]; }
+    c->cap_rows = rows;
+    return 0;
+}
+int ensure_tap(bsrnn_ctx* c, size_t rows)
+{
+    if (rows <= c->tap_rows) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->d_tap) { HIP_TRY(hipFree(c->d_tap)); c->d_tap = nullptr; }
+    HIP_TRY(hipMalloc((void**)&c->d_tap, rows * F2 * sizeof(float)));
+    c->tap_rows = rows;
+    return 0;
+}
+
+void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ldy, const float* R, int ldr,
+               const float* Mul, int ldm, float* tap, int M, int epi, hipStream_t s)
+{
+    GemmLaunch g;
+    g.jobs = c->d_jobs + c->job0[slot];
+    g.tiles = c->d_tiles + c->tile0[slot];
+    g.n_tiles = c->ntiles[slot];
+    g.X = X; g.ldx = ldx; g.Y = Y; g.ldy = ldy; g.R = R; g.ldr = ldr; g.Mul = Mul; g.ldm = ldm;
+    g.tap = tap; g.ldt = F2; g.M = M; g.epilogue = epi;
+    launch_gemm(g, s);
+}
+
+// The model proper on frame-major rows: Xf [M][2050] -> Yf [M][2050], M = C*T, row = c*T + t.
+int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T,
+              const float* state_in, float* state_out, hipStream_t s)
+{
+    const int M = C * T, K = c->K, KH = K * HID;
+    {   // BandSplit: bandFCs_pre (2 linears) -> residual P; bandFCs (3 linears) -> Z0   bsrnn.py:404-415
+        StageScope sc(c, ST_BANDSPLIT, s);
+        gemm_slot(c, PRE0, Xf, F2, c->A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, PRE2, c->A1, c->LDA, c->P, c->LDP, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC0, c->P, c->LDP, c->A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC2, c->A1, c->LDA, c->A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC4, c->A2, c->LDA, c->Z0, KH, nullptr, 0, nullptr, 0, nullptr, M, EPI_LINEAR, s);
+    }
+    const size_t slab = (size_t)2 * 2 * C * K * HID;     // one Time block's (h,c) x 2 layers
+    for (int blk = 0; blk < 2; ++blk) {
+        {   // BandwiseLSTM: N = M sequences of length K   bsrnn.py:138-153
+            StageScope sc(c, ST_BAND_LSTM, s);
+            launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandB[blk][0], M, K, 64, s);
+            launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandB[blk][1], M, K, 128, s);
+        }
+        {
+            StageScope sc(c, ST_BAND_FC, s);
+            gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+        }
+        {   // TimewiseLSTM: N = C*K sequences of length T, causal, state carry   bsrnn.py:106-128
+            StageScope sc(c, ST_TIME_LSTM, s);
+            launch_time_lstm(c->Z1, c->H1, c->timeW[blk], c->timeB[blk],
+                             state_in ? state_in + blk * slab : nullptr, state_out ? state_out + blk * slab : nullptr,
+                             C, T, K, s);
+        }
+        {
+            StageScope sc(c, ST_TIME_FC, s);
+            gemm_slot(c, BLK_FC1 + 2 * blk, c->H1, HID, c->Z0, HID, c->Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+        }
+    }
+    {   // MaskEstimation: bandFCs_back (3) + bandFCs_back_post (2) + skip + x*mask   bsrnn.py:420-443
+        StageScope sc(c, ST_MASK, s);
+        gemm_slot(c, BACK0, c->Z0, KH, c->A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, BACK2, c->A1, c->LDA, c->A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, BACK4, c->A2, c->LDA, c->A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, POST0, c->A1, c->LDA, c->A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, POST2, c->A2, c->LDA, Yf, F2, c->P, c->LDP, Xf, F2, tap, M, EPI_MASK, s);
+    }
+    c->last_stream = s;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_ready(bsrnn_ctx* c)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (!c->committed) return fail(BSRNN_ESTATE, "bsrnn_commit_params() has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================== ABI
+extern "C" {
+
+int bsrnn_abi_version(void) { return BSRNN_ABI_VERSION; }
+const char* bsrnn_last_error(void) { return g_err; }
+
+int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx** out)
+{
+    if (!out || !widths || n_bands < 1 || n_bands > 256) return fail(BSRNN_EARG, "bad band table");
+    int sum = 0;
+    for (int i = 0; i < n_bands; ++i) {
+        if (widths[i] < 0) return fail(BSRNN_EARG, "negative band width");
+        sum += widths[i];
+    }
+    if (sum != NBINS) return fail(BSRNN_EARG, "band widths sum to %d, expected %d", sum, NBINS);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BSRNN_EARG, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    bsrnn_ctx* c = new bsrnn_ctx();
+    c->device = device;
+    c->K = n_bands;
+    c->widths.assign(widths, widths + n_bands);
+    int pos = 0, ao = 0, po = 0;
+    for (int i = 0; i < n_bands; ++i) {
+        c->off.push_back(pos); pos += widths[i];
+        c->aoff.push_back(ao); ao += round4(imax(2 * widths[i], 2 * HID));
+        c->poff.push_back(po); po += round4(2 * widths[i]);
+    }
+    c->LDA = ao; c->LDP = imax(po, 4);
+    build_inventory(c);
+    memset(c->acc_ms, 0, sizeof c->acc_ms);
+    memset(c->acc_n, 0, sizeof c->acc_n);
+
+    // FFT tables in double precision
+    std::vector<float> t(2 * 1024 + 2 * 1025 + 2048 + 1024 + 1024 + 16);
+    size_t o = 0;
+    const double PI = 3.14159265358979323846;
+    size_t o_tw1 = o;
+    for (int k = 0; k < 1024; ++k) { t[o++] = (float)cos(2 * PI * k / 1024); t[o++] = (float)(-sin(2 * PI * k / 1024)); }
+    size_t o_tw2 = o;
+    for (int k = 0; k <= 1024; ++k) { t[o++] = (float)cos(2 * PI * k / 2048); t[o++] = (float)(-sin(2 * PI * k / 2048)); }
+    o = (o + 3) & ~size_t(3);
+    size_t o_hann = o;
+    std::vector<float> w(2048);
+    for (int i = 0; i < 2048; ++i) { w[i] = (float)(0.5 - 0.5 * cos(2 * PI * i / 2048)); t[o++] = w[i]; }
+    size_t o_env = o;
+    for (int i = 0; i < 1024; ++i) {     // torch.istft envelope: overlap-add of window^2 (float), inverted
+        const float e = w[i] * w[i] + w[i + 1024] * w[i + 1024];
+        t[o++] = 1.0f / e;
+    }
+    size_t o_ws = o;
+    for (int i = 0; i < 1024; ++i) t[o++] = 1.0f / (w[i] + w[i + 1024]);
+    hipError_t e = hipMalloc((void**)&c->d_tables, o * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(c->d_tables, t.data(), o * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete c; return fail(BSRNN_EHIP, "table upload: %s", hipGetErrorString(e)); }
+    c->tb.tw1024 = (const float2*)(c->d_tables + o_tw1);
+    c->tb.tw2048 = (const float2*)(c->d_tables + o_tw2);
+    c->tb.hann = c->d_tables + o_hann;
+    c->tb.inv_env = c->d_tables + o_env;
+    c->tb.inv_wsum = c->d_tables + o_ws;
+    *out = c;
+    return 0;
+}
+
+void bsrnn_destroy(bsrnn_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& r : c->pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_tap) (void)hipFree(c->d_tap);
+    if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->d_jobs) (void)hipFree(c->d_jobs);
+    if (c->d_tiles) (void)hipFree(c->d_tiles);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    delete c;
+}
+
+int bsrnn_n_bands(const bsrnn_ctx* c) { return c ? c->K : -1; }
+int bsrnn_device(const bsrnn_ctx* c) { return c ? c->device : -1; }
+int bsrnn_param_count(const bsrnn_ctx* c) { return c ? (int)c->params.size() : -1; }
+
+int bsrnn_param_info(const bsrnn_ctx* c, int32_t i, const char** key, int64_t* d0, int64_t* d1, int32_t* ndim)
+{
+    if (!c || i < 0 || i >= (int)c->params.size()) return fail(BSRNN_EARG, "param index out of range");
+    const Param& p = c->params[i];
+    if (key) *key = p.key.c_str();
+    if (d0) *d0 = p.d0;
+    if (d1) *d1 = p.d1;
+    if (ndim) *ndim = p.ndim;
+    return 0;
+}
+
+int bsrnn_set_param(bsrnn_ctx* c, const char* key, const float* host, int64_t numel)
+{
+    if (!c || !key) return fail(BSRNN_EARG, "null argument");
+    auto it = c->index.find(key);
+    if (it == c->index.end()) return fail(BSRNN_ENOKEY, "unexpected key '%s'", key);
+    Param& p = c->params[it->second];
+    if (numel != p.numel()) return fail(BSRNN_EARG, "size mismatch for %s: got %lld, expected %lld", key, (long long)numel, (long long)p.numel());
+    if (numel > 0 && !host) return fail(BSRNN_EARG, "null data for %s", key);
+    p.data.assign(host, host + numel);
+    p.set = true;
+    c->committed = false;
+    return 0;
+}
+
+int bsrnn_get_param(const bsrnn_ctx* c, const char* key, float* out, int64_t numel)
+{
+    if (!c || !key) return fail(BSRNN_EARG, "null argument");
+    auto it = c->index.find(key);
+    if (it == c->index.end()) return fail(BSRNN_ENOKEY, "unexpected key '%s'", key);
+    const Param& p = c->params[it->second];
+    if (!p.set) return fail(BSRNN_ESTATE, "%s was never set", key);
+    if (numel != p.numel()) return fail(BSRNN_EARG, "size mismatch for %s", key);
+    if (numel) memcpy(out, p.data.data(), numel * sizeof(float));
+    return 0;
+}
+
+int bsrnn_commit_params(bsrnn_ctx* c)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    for (const Param& p : c->params)
+        if (!p.set) return fail(BSRNN_ESTATE, "missing key '%s'", p.key.c_str());
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+
+    Arena ar;
+    std::vector<GemmJob> jobs;
+    std::vector<size_t> jw, jb;          // arena offsets, patched to pointers after upload
+    std::vector<int2> tiles;
+    const int H = HID, K = c->K;
+    char b[128];
+
+    auto add_job = [&](const char* prefix, int N, int Kd, int x_off, int y_off, int r_off, int m_off) {
+        GemmJob j;
+        memset(&j, 0, sizeof j);
+        j.N = N; j.K = Kd; j.x_off = x_off; j.y_off = y_off; j.r_off = r_off; j.m_off = m_off;
+        const Param& w = P_(c, std::string(prefix) + ".weight");
+        const Param& bi = P_(c, std::string(prefix) + ".bias");
+        jw.push_back(ar.put(w.data));
+        jb.push_back(ar.put(bi.data));
+        const int ji = (int)jobs.size();
+        jobs.push_back(j);
+        for (int t = 0; t < (N + 63) / 64; ++t) tiles.push_back(make_int2(ji, t));
+    };
+    auto begin_slot = [&](int slot) { c->job0[slot] = (int)jobs.size(); c->tile0[slot] = (int)tiles.size(); };
+    auto end_slot = [&](int slot) { c->njobs[slot] = (int)jobs.size() - c->job0[slot]; c->ntiles[slot] = (int)tiles.size() - c->tile0[slot]; };
+
+    // per-band MLP chains; tiles[].x is relative to the slot's first job
+    struct Def { int slot; const char* fmt; };
+    for (int slot = PRE0; slot <= POST2; ++slot) {
+        begin_slot(slot);
+        const int j0 = (int)jobs.size();
+        for (int i = 0; i < K; ++i) {
+            const int a = 2 * c->widths[i];
+            const int xin = 2 * c->off[i];         // interleaved re/im column of the band
+            const int m = imax(a, H), pz = imax(a, 2 * H);
+            if (a == 0) {
+                if (slot == FC4) {                 // TrainableConstantModule -> Z[:, :, i, :] = constant
+                    GemmJob j;
+                    memset(&j, 0, sizeof j);
+                    j.N = H; j.K = 0; j.y_off = i * H;
+                    snprintf(b, sizeof b, "bandFCs.%d.0.trainable_constant", i);
+                    const Param& cst = P_(c, b);
+                    jw.push_back(ar.put(cst.data)); jb.push_back(ar.put(cst.data));
+                    jobs.push_back(j);
+                    tiles.push_back(make_int2((int)jobs.size() - 1, 0));
+                }
+                continue;
+            }
+            switch (slot) {
+            case PRE0:  snprintf(b, sizeof b, "bandFCs_pre.%d.0", i); add_job(b, a, a, xin, c->aoff[i], 0, 0); break;
+            case PRE2:  snprintf(b, sizeof b, "bandFCs_pre.%d.2", i); add_job(b, a, a, c->aoff[i], c->poff[i], 0, 0); break;
+            case FC0:   snprintf(b, sizeof b, "bandFCs.%d.0", i); add_job(b, m, a, c->poff[i], c->aoff[i], 0, 0); break;
+            case FC2:   snprintf(b, sizeof b, "bandFCs.%d.2", i); add_job(b, H, m, c->aoff[i], c->aoff[i], 0, 0); break;
+            case FC4:   snprintf(b, sizeof b, "bandFCs.%d.4", i); add_job(b, H, H, c->aoff[i], i * H, 0, 0); break;
+            case BACK0: snprintf(b, sizeof b, "bandFCs_back.%d.0", i); add_job(b, 2 * H, H, i * H, c->aoff[i], 0, 0); break;
+            case BACK2: snprintf(b, sizeof b, "bandFCs_back.%d.2", i); add_job(b, pz, 2 * H, c->aoff[i], c->aoff[i], 0, 0); break;
+            case BACK4: snprintf(b, sizeof b, "bandFCs_back.%d.4", i); add_job(b, a, pz, c->aoff[i], c->aoff[i], 0, 0); break;
+            case POST0: snprintf(b, sizeof b, "bandFCs_back_post.%d.0", i); add_job(b, a, a, c->aoff[i], c->aoff[i], 0, 0); break;
+            case POST2: snprintf(b, sizeof b, "bandFCs_back_post.%d.2", i); add_job(b, a, a, c->aoff[i], xin, c->poff[i], xin); break;
+            }
+        }
+        end_slot(slot);
+        for (int t = c->tile0[slot]; t < (int)tiles.size(); ++t) tiles[t].x -= j0;
+    }
+    // fc of the four NormRNNResidual blocks (bsrnn.py:84), one job each over M*K rows
+    for (int j = 0; j < 4; ++j) {
+        const int slot = BLK_FC0 + j;
+        begin_slot(slot);
+        const int j0 = (int)jobs.size();
+        snprintf(b, sizeof b, "lstms.%d.m.fc", j);
+        add_job(b, H, (j % 2 == 0) ? 2 * H : H, 0, 0, 0, 0);
+        end_slot(slot);
+        for (int t = c->tile0[slot]; t < (int)tiles.size(); ++t) tiles[t].x -= j0;
+    }
+
+    // LSTM weights, folded and packed in the kernels' register order (lstm.hip)
+    size_t o_bandW[2][2], o_bandB[2][2], o_timeW[2], o_timeB[2];
+    std::vector<double> wcat, bsum;
+    for (int blk = 0; blk < 2; ++blk) {
+        const int jb_ = 2 * blk;                               // lstms.0 / lstms.2: bidirectional over bands
+        for (int layer = 0; layer < 2; ++layer) {
+            const int IN = layer == 0 ? H : 2 * H, KT = IN + H, NS = KT / 4;
+            std::vector<float> pk((size_t)2 * 4 * NS * 4 * 64), pb(2 * 256);
+            for (int d = 0; d < 2; ++d) {
+                lstm_cat(c, jb_, layer, d ? "_reverse" : "", IN, wcat, bsum);
+                for (int wv = 0; wv < 4; ++wv)
+                    for (int s = 0; s < NS; ++s)
+                        for (int g = 0; g < 4; ++g)
+                            for (int ln = 0; ln < 64; ++ln) {
+                                const int row = g * 64 + 16 * wv + (ln & 15);
+                                const int k = 16 * (s / 4) + 4 * (ln >> 4) + (s % 4);
+                                pk[((((size_t)d * 4 + wv) * NS + s) * 4 + g) * 64 + ln] = (float)wcat[(size_t)row * KT + k];
+                            }
+                for (int r = 0; r < 256; ++r) pb[d * 256 + r] = (float)bsum[r];
+            }
+            o_bandW[blk][layer] = ar.put(pk);
+            o_bandB[blk][layer] = ar.put(pb);
+        }
+        const int jt = 2 * blk + 1;                            // lstms.1 / lstms.3: causal over time
+        std::vector<float> pk((size_t)2 * 4 * 128 * 64), pb(2 * 256);
+        for (int layer = 0; layer < 2; ++layer) {
+            lstm_cat(c, jt, layer, "", H, wcat, bsum);
+            for (int wv = 0; wv < 4; ++wv)
+                for (int k = 0; k < 128; ++k)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int row = (ln & 3) * 64 + 16 * wv + (ln >> 2);
+                        pk[(((size_t)layer * 4 + wv) * 128 + k) * 64 + ln] = (float)wcat[(size_t)row * 128 + k];
+                    }
+            for (int r = 0; r < 256; ++r) pb[layer * 256 + r] = (float)bsum[r];
+        }
+        o_timeW[blk] = ar.put(pk);
+        o_timeB[blk] = ar.put(pb);
+    }
+
+    // upload
+    if (c->d_arena) { HIP_TRY(hipFree(c->d_arena)); c->d_arena = nullptr; }
+    if (c->d_jobs) { HIP_TRY(hipFree(c->d_jobs)); c->d_jobs = nullptr; }
+    if (c->d_tiles) { HIP_TRY(hipFree(c->d_tiles)); c->d_tiles = nullptr; }
+    HIP_TRY(hipMalloc((void**)&c->d_arena, (ar.h.size() + 4) * sizeof(float)));
+    HIP_TRY(hipMemcpy(c->d_arena, ar.h.data(), ar.h.size() * sizeof(float), hipMemcpyHostToDevice));
+    for (size_t i = 0; i < jobs.size(); ++i) { jobs[i].W = c->d_arena + jw[i]; jobs[i].bias = c->d_arena + jb[i]; }
+    HIP_TRY(hipMalloc((void**)&c->d_jobs, jobs.size() * sizeof(GemmJob)));
+    HIP_TRY(hipMemcpy(c->d_jobs, jobs.data(), jobs.size() * sizeof(GemmJob), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&c->d_tiles, tiles.size() * sizeof(int2)));
+    HIP_TRY(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
+    for (int blk = 0; blk < 2; ++blk) {
+        for (int layer = 0; layer < 2; ++layer) {
+            c->bandW[blk][layer] = c->d_arena + o_bandW[blk][layer];
+            c->bandB[blk][layer] = c->d_arena + o_bandB[blk][layer];
+        }
+        c->timeW[blk] = c->d_arena + o_timeW[blk];
+        c->timeB[blk] = c->d_arena + o_timeB[blk];
+    }
+    c->committed = true;
+    return 0;
+}
+
+int bsrnn_load_weights_file(bsrnn_ctx* c, const char* path)
+{
+    if (!c || !path) return fail(BSRNN_EARG, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(BSRNN_EIO, "cannot open %s", path);
+    auto bad = [&](const char* why) { fclose(f); return fail(BSRNN_EIO, "%s: %s", path, why); };
+    char magic[8];
+    uint32_t nb = 0, nt = 0;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "BSRNNW01", 8)) return bad("bad magic");
+    if (fread(&nb, 4, 1, f) != 1 || (int)nb != c->K) return bad("band count differs from the context's table");
+    for (uint32_t i = 0; i < nb; ++i) {
+        uint32_t w;
+        if (fread(&w, 4, 1, f) != 1 || (int)w != c->widths[i]) return bad("band table differs from the context's table");
+    }
+    if (fread(&nt, 4, 1, f) != 1) return bad("truncated");
+    std::vector<float> buf;
+    std::string key;
+    for (uint32_t t = 0; t < nt; ++t) {
+        uint32_t kl = 0, nd = 0;
+        if (fread(&kl, 4, 1, f) != 1 || kl > 4096) return bad("bad key length");
+        key.resize(kl);
+        if (kl && fread(&key[0], 1, kl, f) != kl) return bad("truncated key");
+        if (fread(&nd, 4, 1, f) != 1 || nd > 8) return bad("bad ndim");
+        uint64_t n = 1;
+        for (uint32_t d = 0; d < nd; ++d) {
+            uint64_t dim;
+            if (fread(&dim, 8, 1, f) != 1) return bad("truncated dims");
+            n *= dim;
+        }
+        buf.resize(n);
+        if (n && fread(buf.data(), 4, n, f) != n) return bad("truncated data");
+        int rc = bsrnn_set_param(c, key.c_str(), buf.data(), (int64_t)n);
+        if (rc) { fclose(f); return rc; }
+    }
+    fclose(f);
+    return bsrnn_commit_params(c);
+}
+
+// --------------------------------------------------------------------------- model entry points
+int bsrnn_forward(bsrnn_ctx* c, const float* x, float* y, float* mask, int32_t C, int32_t T, void* stream)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!x || !y || C < 1 || T < 1) return fail(BSRNN_EARG, "bsrnn_forward: bad arguments (C=%d, T=%d)", C, T);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t M = (size_t)C * T;
+    if ((rc = ensure_ws(c, M))) return rc;
+    if (mask && (rc = ensure_tap(c, M))) return rc;
+    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(x, c->Xf, C, T, s); }
+    if ((rc = run_model(c, c->Xf, c->Yf, mask ? c->d_tap : nullptr, C, T, nullptr, nullptr, s))) return rc;
+    {
+        StageScope sc(c, ST_LAYOUT, s);
+        launch_from_frame_major(c->Yf, y, C, T, s);
+        if (mask) launch_from_frame_major(c->d_tap, mask, C, T, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_forward_chunk(bsrnn_ctx* c, const float* x, const float* state_in, float* y, float* state_out,
+                        int32_t C, int32_t L, void* stream)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!x || !y || !state_in || !state_out || C < 1 || L < 1) return fail(BSRNN_EARG, "bsrnn_forward_chunk: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t M = (size_t)C * L;
+    if ((rc = ensure_ws(c, M))) return rc;
+    if (L == 1) {       // [C,2050] is already frame-major
+        return run_model(c, x, y, nullptr, C, 1, state_in, state_out, s);
+    }
+    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(x, c->Xf, C, L, s); }
+    if ((rc = run_model(c, c->Xf, c->Yf, nullptr, C, L, state_in, state_out, s))) return rc;
+    { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->Yf, y, C, L, s); }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_forward_recurrent(bsrnn_ctx* c, const float* x, const float* state_in, float* y, float* state_out,
+                            int32_t C, void* stream)
+{
+    return bsrnn_forward_chunk(c, x, state_in, y, state_out, C, 1, stream);
+}
+
+int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* state_in, float* state_out,
+                    int32_t C, int32_t T, void* stream)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!z || !z_out || C < 1 || T < 1) return fail(BSRNN_EARG, "bsrnn_dual_path: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int M = C * T, K = c->K;
+    if ((rc = ensure_ws(c, M))) return rc;
+    const size_t nz = (size_t)M * K * HID;
+    HIP_TRY(hipMemcpyAsync(c->Z0, z, nz * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const size_t slab = (size_t)2 * 2 * C * K * HID;
+    for (int blk = 0; blk < 2; ++blk) {
+        launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandB[blk][0], M, K, 64, s);
+        launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandB[blk][1], M, K, 128, s);
+        gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+        launch_time_lstm(c->Z1, c->H1, c->timeW[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
+                         state_out ? state_out + blk * slab : nullptr, C, T, K, s);
+        gemm_slot(c, BLK_FC1 + 2 * blk, c->H1, HID, c->Z0, HID, c->Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+    }
+    HIP_TRY(hipMemcpyAsync(z_out, c->Z0, nz * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// --------------------------------------------------------------------------- STFT sandwich
+int bsrnn_stft(bsrnn_ctx* c, const float* wave, float* x, int32_t R, int64_t n, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!wave || !x || R < 1 || n <= NFFT / 2) return fail(BSRNN_EARG, "bsrnn_stft: need n > 1024 samples (reflect padding), got %lld", (long long)n);
+    hipStream_t s = (hipStream_t)stream;
+    const int T = 1 + (int)(n / HOPS);
+    int rc = ensure_ws(c, (size_t)R * T);
+    if (rc) return rc;
+    { StageScope sc(c, ST_STFT, s); launch_stft(c->tb, wave, c->Xf, R, n, T, s); }
+    { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->Xf, x, R, T, s); }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_istft(bsrnn_ctx* c, const float* y, float* wave_out, int32_t R, int32_t T, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!y || !wave_out || R < 1 || T < 2) return fail(BSRNN_EARG, "bsrnn_istft: need T >= 2 frames");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_ws(c, (size_t)R * T);
+    if (rc) return rc;
+    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(y, c->Yf, R, T, s); }
+    {
+        StageScope sc(c, ST_ISTFT, s);
+        launch_istft_frames(c->tb, c->Yf, c->frames, R * T, s);
+        launch_istft_ola(c->tb, c->frames, wave_out, R, T, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, int64_t n, void* stream)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!wave || !wave_out || R < 1 || n <= NFFT / 2) return fail(BSRNN_EARG, "bsrnn_separate: need n > 1024 samples, got %lld", (long long)n);
+    hipStream_t s = (hipStream_t)stream;
+    const int T = 1 + (int)(n / HOPS);
+    if ((rc = ensure_ws(c, (size_t)R * T))) return rc;
+    { StageScope sc(c, ST_STFT, s); launch_stft(c->tb, wave, c->Xf, R, n, T, s); }
+    if ((rc = run_model(c, c->Xf, c->Yf, nullptr, R, T, nullptr, nullptr, s))) return rc;
+    {
+        StageScope sc(c, ST_ISTFT, s);
+        launch_istft_frames(c->tb, c->Yf, c->frames, R * T, s);
+        launch_istft_ola(c->tb, c->frames, wave_out, R, T, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// --------------------------------------------------------------------------- streaming
+int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!out || C < 1) return fail(BSRNN_EARG, "bsrnn_stream_create: bad arguments");
+    bsrnn_stream* st = new bsrnn_stream();
+    st->ctx = c; st->C = C;
+    const size_t nstate = (size_t)4 * 2 * C * c->K * HID;
+    const size_t total = (size_t)C * (NFFT * 2 + F2 * 2 + HOPS * 2) + nstate;
+    float* p = nullptr;
+    hipError_t e = hipMalloc((void**)&p, total * sizeof(float));
+    if (e != hipSuccess) { delete st; return fail(BSRNN_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    st->buf = p; p += (size_t)C * NFFT;
+    st->prev = p; p += (size_t)C * NFFT;
+    st->X = p; p += (size_t)C * F2;
+    st->Y = p; p += (size_t)C * F2;
+    st->chunk = p; p += (size_t)C * HOPS;
+    st->out = p; p += (size_t)C * HOPS;
+    st->state = p;
+    e = hipMemset(st->buf, 0, total * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(st->buf); delete st; return fail(BSRNN_EHIP, "hipMemset: %s", hipGetErrorString(e)); }
+    rc = ensure_ws(c, C);
+    if (rc) { (void)hipFree(st->buf); delete st; return rc; }
+    *out = st;
+    return 0;
+}
+
+void bsrnn_stream_destroy(bsrnn_stream* st)
+{
+    if (!st) return;
+    (void)hipSetDevice(st->ctx->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(st->buf);
+    delete st;
+}
+
+int bsrnn_stream_reset(bsrnn_stream* st, void* stream)
+{
+    if (!st) return fail(BSRNN_EARG, "null stream");
+    HIP_TRY(hipSetDevice(st->ctx->device));
+    const size_t nstate = (size_t)4 * 2 * st->C * st->ctx->K * HID;
+    const size_t total = (size_t)st->C * (NFFT * 2 + F2 * 2 + HOPS * 2) + nstate;
+    HIP_TRY(hipMemsetAsync(st->buf, 0, total * sizeof(float), (hipStream_t)stream));
+    return 0;
+}
+
+int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mix, void* stream)
+{
+    if (!st || !chunk || !out) return fail(BSRNN_EARG, "bsrnn_stream_step: null argument");
+    bsrnn_ctx* c = st->ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_analysis(c->tb, st->buf, chunk, st->X, st->C, s); }
+    if ((rc = run_model(c, st->X, st->Y, nullptr, st->C, 1, st->state, st->state, s))) return rc;
+    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_synthesis(c->tb, st->Y, st->X, mix, st->prev, out, st->C, s); }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_stream_step_host(bsrnn_stream* st, const float* chunk_host, float* out_host, float mix)
+{
+    if (!st || !chunk_host || !out_host) return fail(BSRNN_EARG, "bsrnn_stream_step_host: null argument");
+    HIP_TRY(hipSetDevice(st->ctx->device));
+    const size_t nb = (size_t)st->C * HOPS * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(st->chunk, chunk_host, nb, hipMemcpyHostToDevice, nullptr));
+    int rc = bsrnn_stream_step(st, st->chunk, st->out, mix, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, st->out, nb, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+int bsrnn_stream_get_state(bsrnn_stream* st, float* state_host)
+{
+    if (!st || !state_host) return fail(BSRNN_EARG, "null argument");
+    HIP_TRY(hipSetDevice(st->ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t nstate = (size_t)4 * 2 * st->C * st->ctx->K * HID;
+    HIP_TRY(hipMemcpy(state_host, st->state, nstate * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// --------------------------------------------------------------------------- measurement
+int bsrnn_set_profiling(bsrnn_ctx* c, int32_t on)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (on && c->pool.empty()) {
+        c->pool.resize(8192);
+        for (auto& r : c->pool) { HIP_TRY(hipEventCreate(&r.a)); HIP_TRY(hipEventCreate(&r.b)); }
+    }
+    c->prof = on != 0;
+    return 0;
+}
+int bsrnn_stage_count(void) { return NSTAGE; }
+const char* bsrnn_stage_name(int32_t i) { return (i >= 0 && i < NSTAGE) ? kStageNames[i] : ""; }
+
+int bsrnn_stage_times(bsrnn_ctx* c, double* ms_out, int64_t* n_out, int32_t reset)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t i = 0; i < c->pool_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->pool[i].a, c->pool[i].b) == hipSuccess) {
+            c->acc_ms[c->pool[i].stage] += ms;
+            c->acc_n[c->pool[i].stage] += 1;
+        }
+    }
+    c->pool_used = 0;
+    for (int i = 0; i < NSTAGE; ++i) {
+        if (ms_out) ms_out[i] = c->acc_ms[i];
+        if (n_out) n_out[i] = c->acc_n[i];
+    }
+    if (reset) { memset(c->acc_ms, 0, sizeof c->acc_ms); memset(c->acc_n, 0, sizeof c->acc_n); }
+    return 0;
+}
+
+// --------------------------------------------------------------------------- device memory helpers
+int bsrnn_dev_alloc(bsrnn_ctx* c, int64_t nbytes, void** out)
+{
+    if (!c || !out || nbytes < 0) return fail(BSRNN_EARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(out, (size_t)nbytes));
+    return 0;
+}
+int bsrnn_dev_free(bsrnn_ctx* c, void* p)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipFree(p));
+    return 0;
+}
+int bsrnn_copy_h2d(bsrnn_ctx* c, void* dst, const void* src, int64_t nbytes)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(dst, src, (size_t)nbytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int bsrnn_copy_d2h(bsrnn_ctx* c, void* dst, const void* src, int64_t nbytes)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int bsrnn_sync(bsrnn_ctx* c, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

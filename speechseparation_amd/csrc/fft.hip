@@ -1,0 +1,267 @@
+// STFT / iSTFT / layout kernels of the callers' sandwich (infer.py:29-37, m_dataset.py:187-195,
+// infer-streaming.py:116-145, speech-ladspa-onnx.cpp:191-261).
+//
+// One 256-thread workgroup transforms one frame.  The real 2048-point transform is done as a
+// complex 1024-point radix-4 Stockham FFT in LDS (5 passes, one radix-4 butterfly per thread
+// per pass) plus the real-FFT split/merge step; twiddles and windows come from tables built
+// in double precision on the host.  These stages are HBM-bound (4 KiB in, 8.2 KiB out per
+// frame); their loads and stores are coalesced along the frame.
+#include "kernels.h"
+
+namespace bsrnn {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+// In-LDS complex FFT of 1024 points, Stockham autosort radix-4.  z0 holds the input, the
+// result ends in the returned buffer.  INV = true computes the unnormalised inverse.
+template <bool INV>
+__device__ __forceinline__ float2* fft1024(float2* z0, float2* z1, const float2* __restrict__ tw, int tid)
+{
+    float2* src = z0;
+    float2* dst = z1;
+#pragma unroll
+    for (int p = 1; p < 1024; p <<= 2) {
+        const int k = tid & (p - 1);
+        const int jo = ((tid - k) << 2) + k;
+        const int step = 256 / p;                 // W_{4p}^k = W_1024^{k*256/p}
+        float2 u0 = src[tid], u1 = src[tid + 256], u2 = src[tid + 512], u3 = src[tid + 768];
+        if (p > 1) {
+            float2 t1 = tw[k * step], t2 = tw[2 * k * step], t3 = tw[3 * k * step];
+            if (INV) { t1 = cconj(t1); t2 = cconj(t2); t3 = cconj(t3); }
+            u1 = cmul(u1, t1); u2 = cmul(u2, t2); u3 = cmul(u3, t3);
+        }
+        const float2 v0 = cadd(u0, u2), v1 = csub(u0, u2), v2 = cadd(u1, u3), d = csub(u1, u3);
+        const float2 v3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);   // (+i or -i) * d
+        dst[jo] = cadd(v0, v2);
+        dst[jo + p] = cadd(v1, v3);
+        dst[jo + 2 * p] = csub(v0, v2);
+        dst[jo + 3 * p] = csub(v1, v3);
+        __syncthreads();
+        float2* tmp = src; src = dst; dst = tmp;
+    }
+    return src;
+}
+
+// real spectrum X[0..1024] from Z = FFT1024(x[2n] + i x[2n+1]); writes interleaved re/im
+__device__ __forceinline__ void rfft_split_store(const float2* Z, const float2* __restrict__ tw2048,
+                                                 float* __restrict__ out, int tid)
+{
+    for (int k = tid; k <= 1024; k += 256) {
+        const float2 zk = Z[k & 1023];
+        const float2 zc = cconj(Z[(1024 - k) & 1023]);
+        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+        const float2 dd = csub(zk, zc);                               // (zk - zc) / (2i)
+        const float2 o = make_float2(0.5f * dd.y, -0.5f * dd.x);
+        float2 x = cadd(e, cmul(tw2048[k], o));
+        if (k == 0 || k == 1024) x.y = 0.f;                           // exactly real for real input
+        *reinterpret_cast<float2*>(out + 2 * k) = x;
+    }
+}
+
+// Z[k] = E[k] + i O[k] for the inverse; imaginary parts of DC / Nyquist are ignored like c2r does
+__device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const float2* __restrict__ tw2048,
+                                            float2* z, int tid)
+{
+    for (int k = tid; k < 1024; k += 256) {
+        float2 xk = *reinterpret_cast<const float2*>(Y + 2 * k);
+        float2 xc = *reinterpret_cast<const float2*>(Y + 2 * (1024 - k));
+        if (k == 0) { xk.y = 0.f; xc.y = 0.f; }
+        xc = cconj(xc);
+        const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
+        const float2 dd = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
+        const float2 o = cmul(dd, cconj(tw2048[k]));
+        z[k] = make_float2(e.x - o.y, e.y + o.x);                     // e + i*o
+    }
+}
+
+// ------------------------------------------------------------------------------ offline STFT
+__global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __restrict__ wave, float* __restrict__ X,
+                                                   int64_t n, int T)
+{
+    __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
+    const int tid = threadIdx.x;
+    const int m = blockIdx.x;                  // r*T + t
+    const int r = m / T, t = m % T;
+    const float* src = wave + (size_t)r * n;
+    // padded frame sample i (0..2047) is original index t*1024 + i - 1024, reflected at both ends
+    for (int c = tid; c < 1024; c += 256) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * c + e;
+            int64_t idx = (int64_t)t * HOPS + i - NFFT / 2;
+            if (idx < 0) idx = -idx;
+            if (idx >= n) idx = 2 * (n - 1) - idx;
+            v[e] = src[idx] * tb.hann[i];
+        }
+        z0[c] = make_float2(v[0], v[1]);
+    }
+    __syncthreads();
+    const float2* Z = fft1024<false>(z0, z1, tb.tw1024, tid);
+    rfft_split_store(Z, tb.tw2048, X + (size_t)m * F2, tid);
+}
+
+void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s)
+{
+    hipLaunchKernelGGL(stft_kernel, dim3(R * T), dim3(256), 0, s, tb, wave, X, n, T);
+}
+
+// ------------------------------------------------------------------------------ offline iSTFT
+__global__ __launch_bounds__(256) void istft_frames_kernel(FftTables tb, const float* __restrict__ Y, float* __restrict__ frames)
+{
+    __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
+    const int tid = threadIdx.x;
+    const size_t m = blockIdx.x;
+    irfft_merge(Y + m * F2, tb.tw2048, z0, tid);
+    __syncthreads();
+    const float2* z = fft1024<true>(z0, z1, tb.tw1024, tid);
+    float* dst = frames + m * NFFT;
+    const float sc = 1.0f / 1024.0f;
+    for (int c = tid; c < 1024; c += 256) {
+        const float2 v = z[c];
+        *reinterpret_cast<float2*>(dst + 2 * c) =
+            make_float2(v.x * sc * tb.hann[2 * c], v.y * sc * tb.hann[2 * c + 1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void istft_ola_kernel(FftTables tb, const float* __restrict__ frames, float* __restrict__ out, int T)
+{
+    // out[r][s], s in [0, (T-1)*1024): padded position p = s + 1024 is covered by frame t1 = p/1024
+    // at offset off and by frame t1-1 at offset off + 1024
+    const int r = blockIdx.y;
+    const int64_t len = (int64_t)(T - 1) * HOPS;
+    const int64_t s4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (s4 >= len) return;
+    const int64_t p = s4 + HOPS;
+    const int t1 = (int)(p / HOPS);
+    const int off = (int)(p % HOPS);
+    const float* f1 = frames + ((size_t)r * T + t1) * NFFT + off;
+    const float* f0 = frames + ((size_t)r * T + t1 - 1) * NFFT + off + HOPS;
+    const float4 a = *reinterpret_cast<const float4*>(f1);
+    const float4 b = *reinterpret_cast<const float4*>(f0);
+    const float4 e = *reinterpret_cast<const float4*>(tb.inv_env + off);
+    *reinterpret_cast<float4*>(out + (size_t)r * len + s4) =
+        make_float4((a.x + b.x) * e.x, (a.y + b.y) * e.y, (a.z + b.z) * e.z, (a.w + b.w) * e.w);
+}
+
+void launch_istft_frames(const FftTables& tb, const float* Y, float* frames, int M, hipStream_t s)
+{
+    hipLaunchKernelGGL(istft_frames_kernel, dim3(M), dim3(256), 0, s, tb, Y, frames);
+}
+void launch_istft_ola(const FftTables& tb, const float* frames, float* out, int R, int T, hipStream_t s)
+{
+    if (T < 2) return;
+    const int64_t len = (int64_t)(T - 1) * HOPS;
+    dim3 grid((unsigned)((len / 4 + 255) / 256), R);
+    hipLaunchKernelGGL(istft_ola_kernel, grid, dim3(256), 0, s, tb, frames, out, T);
+}
+
+// ------------------------------------------------------------------------------ [C][2050][T] <-> [C*T][2050]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols)
+{
+    // src [batch][rows][cols] -> dst [batch][cols][rows]
+    __shared__ float tile[32][33];
+    const size_t boff = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + i][tx] = src[boff + (size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (r < rows && c < cols) dst[boff + (size_t)c * rows + r] = tile[tx][ty + i];
+    }
+}
+
+void launch_to_frame_major(const float* x, float* xf, int C, int T, hipStream_t s)
+{
+    dim3 grid((T + 31) / 32, (F2 + 31) / 32, C);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, x, xf, F2, T);
+}
+void launch_from_frame_major(const float* yf, float* y, int C, int T, hipStream_t s)
+{
+    dim3 grid((F2 + 31) / 32, (T + 31) / 32, C);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, yf, y, T, F2);
+}
+
+// ------------------------------------------------------------------------------ streaming DSP
+__global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, float* __restrict__ buf, const float* __restrict__ chunk,
+                                                              float* __restrict__ X)
+{
+    __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x;
+    float* b = buf + (size_t)c * NFFT;
+    const float* ch = chunk + (size_t)c * HOPS;
+    // new buffer = [old[1024:2048], chunk]   (infer-streaming.py:116)
+    float2 keep[2], fresh[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cc = tid + 256 * i;                 // complex index 0..511 of each half
+        keep[i] = *reinterpret_cast<const float2*>(b + HOPS + 2 * cc);
+        fresh[i] = *reinterpret_cast<const float2*>(ch + 2 * cc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cc = tid + 256 * i;
+        *reinterpret_cast<float2*>(b + 2 * cc) = keep[i];
+        *reinterpret_cast<float2*>(b + HOPS + 2 * cc) = fresh[i];
+        z0[cc] = make_float2(keep[i].x * tb.hann[2 * cc], keep[i].y * tb.hann[2 * cc + 1]);
+        z0[512 + cc] = make_float2(fresh[i].x * tb.hann[HOPS + 2 * cc], fresh[i].y * tb.hann[HOPS + 2 * cc + 1]);
+    }
+    __syncthreads();
+    const float2* Z = fft1024<false>(z0, z1, tb.tw1024, tid);
+    rfft_split_store(Z, tb.tw2048, X + (size_t)c * F2, tid);
+}
+
+__global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, const float* __restrict__ Y, const float* __restrict__ X,
+                                                               float mix, float* __restrict__ prev, float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
+    __shared__ __attribute__((aligned(16))) float spec[F2 + 2];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x;
+    const float* y = Y + (size_t)c * F2;
+    const float* x = X + (size_t)c * F2;
+    // wet/dry on the spectrum (speech-ladspa-onnx.cpp:215-226); mix = 1 is the plain model output
+    const float dry = mix >= 0.f ? 1.f - mix : 1.f;
+    for (int i = tid; i < F2; i += 256) spec[i] = (mix == 1.f) ? y[i] : mix * y[i] + dry * x[i];
+    __syncthreads();
+    irfft_merge(spec, tb.tw2048, z0, tid);
+    __syncthreads();
+    const float2* z = fft1024<true>(z0, z1, tb.tw1024, tid);
+    float* pv = prev + (size_t)c * NFFT;
+    float* o = out + (size_t)c * HOPS;
+    const float sc = 1.0f / 1024.0f;
+    // out = (s_now[0:1024] + s_prev[1024:2048]) / (w[0:1024] + w[1024:2048]); prev = s_now
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cc = tid + 256 * i;                 // samples 2cc, 2cc+1 of the first half
+        const float2 now = make_float2(z[cc].x * sc, z[cc].y * sc);
+        const float2 old = *reinterpret_cast<const float2*>(pv + HOPS + 2 * cc);
+        *reinterpret_cast<float2*>(o + 2 * cc) =
+            make_float2((now.x + old.x) * tb.inv_wsum[2 * cc], (now.y + old.y) * tb.inv_wsum[2 * cc + 1]);
+    }
+    __syncthreads();
+    for (int cc = tid; cc < 1024; cc += 256)
+        *reinterpret_cast<float2*>(pv + 2 * cc) = make_float2(z[cc].x * sc, z[cc].y * sc);
+}
+
+void launch_stream_analysis(const FftTables& tb, float* buf, const float* chunk, float* X, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(stream_analysis_kernel, dim3(C), dim3(256), 0, s, tb, buf, chunk, X);
+}
+void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, float mix, float* prev, float* out, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(stream_synthesis_kernel, dim3(C), dim3(256), 0, s, tb, Y, X, mix, prev, out);
+}
+
+}  // namespace bsrnn

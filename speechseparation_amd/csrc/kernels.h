@@ -1,0 +1,84 @@
+// Internal launcher interface between api.hip and the gfx950 kernels.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bsrnn {
+
+constexpr int HID = 64;       // band_features (bsrnn.py:60)
+constexpr int NFFT = 2048;    // infer.py:31
+constexpr int HOPS = 1024;
+constexpr int NBINS = 1025;
+constexpr int F2 = 2050;      // interleaved re/im columns
+
+// ------------------------------------------------------------------ grouped linear layers
+// One job = one nn.Linear of one band.  A launch runs every job of one "layer slot" of the
+// per-band MLP chains over all M = C*T frame rows.
+struct GemmJob {
+    const float* W;      // [N][K] row-major (torch Linear layout), device, 8-byte aligned rows
+    const float* bias;   // [N]
+    int N, K;            // K may be 0: y = bias (TrainableConstantModule, bsrnn.py:12-24)
+    int x_off;           // column offset of the job's input inside an X row
+    int y_off;           // column offset of the output inside a Y row
+    int r_off;           // column offset inside the residual row (EPI_RES, EPI_MASK)
+    int m_off;           // column offset inside the multiplier / mask-tap row (EPI_MASK)
+};
+
+enum GemmEpilogue {
+    EPI_LINEAR = 0,      // y = acc + b
+    EPI_LEAKY = 1,       // y = leaky_relu(acc + b, 0.01)
+    EPI_RES = 2,         // y = acc + b + R                         (NormRNNResidual, bsrnn.py:84-86)
+    EPI_MASK = 3         // mask = acc + b + R ; y = Mul * mask      (bsrnn.py:425, :441)
+};
+
+struct GemmLaunch {
+    const GemmJob* jobs;     // device array
+    const int2* tiles;       // device array [n_tiles]: (job index, n-tile index inside the job)
+    int n_tiles;
+    const float* X; int ldx;
+    float* Y; int ldy;
+    const float* R; int ldr;
+    const float* Mul; int ldm;
+    float* tap; int ldt;     // optional mask tap (EPI_MASK), may be null
+    int M;
+    int epilogue;
+};
+void launch_gemm(const GemmLaunch& g, hipStream_t stream);
+
+// ------------------------------------------------------------------ dual-path LSTM kernels
+// Band-axis BLSTM layer (both directions in one launch): N sequences of length L.
+//   xin  [N][L][IN]           IN = 64 (layer 0, fc_in folded into W_ih) or 128 (layer 1)
+//   hout [N][L][128]          forward half at [0,64), backward half at [64,128)
+//   wpk  packed [2 dir][4 wave][(IN+64)/4 step][4 gate][64 lane], bias [2][256]
+void launch_band_lstm(const float* xin, float* hout, const float* wpk, const float* bias,
+                      int N, int L, int IN, hipStream_t stream);
+// Time-axis LSTM, both layers pipelined in one launch, causal with state carry.
+//   zin/hout [R][T][K][64]; sequences n = r*K + k;  wpk packed [2 layer][4 wave][128 k][64 lane]
+//   state_in/out [2 (h,c)][2 layer][R*K][64] or null
+void launch_time_lstm(const float* zin, float* hout, const float* wpk, const float* bias,
+                      const float* state_in, float* state_out, int R, int T, int K, hipStream_t stream);
+
+// ------------------------------------------------------------------ STFT / iSTFT / layout
+struct FftTables {           // device tables, built once per context (double precision on host)
+    const float2* tw1024;    // exp(-2 pi i k / 1024), k < 1024
+    const float2* tw2048;    // exp(-2 pi i k / 2048), k <= 1024
+    const float* hann;       // periodic Hann(2048)
+    const float* inv_env;    // 1 / (w^2[i] + w^2[i+1024]), i < 1024   (torch.istft envelope)
+    const float* inv_wsum;   // 1 / (w[i] + w[i+1024]),   i < 1024   (infer-streaming.py:145)
+};
+// wave [R][n] -> X frame-major [R*T][2050] (re/im interleaved), reflect padding, Hann.
+void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s);
+// Y frame-major [R*T][2050] -> windowed synthesis frames [R*T][2048] -> wave_out [R][(T-1)*1024]
+void launch_istft_frames(const FftTables& tb, const float* Y, float* frames, int M, hipStream_t s);
+void launch_istft_ola(const FftTables& tb, const float* frames, float* out, int R, int T, hipStream_t s);
+// [C][2050][T] <-> [C*T][2050]
+void launch_to_frame_major(const float* x, float* xf, int C, int T, hipStream_t s);
+void launch_from_frame_major(const float* yf, float* y, int C, int T, hipStream_t s);
+// streaming DSP, one frame per row (infer-streaming.py:116-145)
+//   analysis: buf [C][2048] slides by 1024, appends chunk [C][1024]; X [C][2050] = rfft(buf*hann)
+//   synthesis: s = irfft(mix(Y, X)); out = (s[0:1024] + prev[1024:2048]) * inv_wsum; prev = s
+void launch_stream_analysis(const FftTables& tb, float* buf, const float* chunk, float* X, int C, hipStream_t s);
+void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, float mix,
+                             float* prev, float* out, int C, hipStream_t s);
+
+}  // namespace bsrnn
