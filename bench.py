@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: separated row-frames/s (+ RTF) of the offline separation sandwich
+waveform -> STFT -> BSRNN.forward -> iSTFT -> waveform on synthetic mixtures.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric config): per GPU R = 64 rows x 8 s @ 16 kHz
+(128 000 samples, T = 126 frames), K = 12 bands, fp32, weights and waveforms from the
+deterministic generators (there are no trained weights / datasets).  Inputs are resident in
+HBM before the timed region.  N > 1: one process per GPU (torch.distributed, RCCL), every rank
+separates its own 64-row shard of a 64*N-row batch -- the path has no exchange step, so the
+only collectives are the timing barrier / max-reduce ("weak" scaling).
+
+One JSON line on rank 0 with the driver's contract fields plus
+  roofline      the dominant kernel family (by HIP-event time measured live in the timed
+                region, on the launch stream): achieved algorithmic rate vs gfx950 peak
+  cpu_baseline  the reference's CPU path (stock torch CPU ops, oracle/bsrnn_torch_cpu.py) timed
+                on this box's host cores on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+# work-unit constants per row-frame (SURVEY.md section 8(d) / BASELINE.md section 4), K = 12, fp32
+BYTES_DUAL_PATH = 24576          # 4 blocks x (read + write of 12 x 64 fp32)
+BYTES_PIPELINE = 96312           # every stage reads its input once, writes its output once
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* (f32 in), dense
+DOMINANT = ("bandsplit_mlp", "mask_mlp")
+
+
+def exact_macs(v):
+    """MACs per row-frame of each stage family for band table v (as the kernels execute them:
+    fc_in folded into W_ih of layer 0)."""
+    H = 64
+    K = len(v)
+    pre = sum(2 * (2 * w) ** 2 for w in v if w)
+    fc = sum(2 * w * max(2 * w, H) + max(2 * w, H) * H + H * H for w in v if w)
+    back = sum(H * 2 * H + 2 * H * max(2 * w, 2 * H) + max(2 * w, 2 * H) * 2 * w for w in v if w)
+    post = pre
+    band = 2 * K * 2 * (4 * H * (H + H) + 4 * H * (2 * H + H))           # 2 blocks x K steps x 2 dirs x (layer0 + layer1)
+    time_ = 2 * K * 2 * 4 * H * (H + H)                                   # 2 blocks x K seqs x 2 layers
+    return {"bandsplit_mlp": pre + fc, "mask_mlp": back + post, "band_lstm": band, "band_fc": 2 * K * 2 * H * H,
+            "time_lstm": time_, "time_fc": 2 * K * H * H}
+
+
+def host_cores():
+    """Threads for the CPU baseline: this process's share of the box (affinity and cgroup quota),
+    capped at BSRNN_CPU_THREADS (default 16 = one GPU's CPU share on the bench pool; asking
+    torch for every core of a 256-thread host from inside a 16-CPU cgroup thrashes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("BSRNN_CPU_THREADS", "16"))))
+
+
+def build_model(device):
+    from speechseparation_amd import weights
+    from speechseparation_amd.bsrnn import BSRNN
+    sd = weights.synth_state_dict(seed=0)
+    m = BSRNN().eval()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return m.to(device), sd
+
+
+def cpu_baseline(sd, rows, n_samples, budget_s=12.0):
+    from oracle.bsrnn_torch_cpu import TorchCpuBSRNN
+    from speechseparation_amd import spec, weights
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    m = TorchCpuBSRNN(sd, spec.generate_bandsplits()[0])
+    wave = torch.from_numpy(weights.synth_waveform(rows, n_samples, seed=1234))
+    m.separate(wave)                      # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 7 and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        m.separate(wave)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    T = 1 + n_samples // 1024
+    return {"value": rows * T / med, "unit": "row-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d iteration(s) of the full workload (%d rows x %d samples, T=%d), median; stock torch CPU ops "
+                      "(nn.LSTM/MKLDNN, addmm, torch.stft/istft) = the reference's CPU path restated" % (len(times), rows, n_samples, T),
+            "seconds_per_pass": med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=64, help="rows per GPU")
+    ap.add_argument("--samples", type=int, default=128000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    torch.set_grad_enabled(False)
+
+    from speechseparation_amd import spec, weights
+    from speechseparation_amd.dist import shard_rows
+    model, sd = build_model(device)
+    lo, hi = shard_rows(args.rows * world, world, rank)          # contiguous row block of the global batch
+    wave = torch.from_numpy(weights.synth_waveform(hi - lo, args.samples, seed=1234, row_offset=lo)).to(device)
+    T = spec.n_frames(args.samples)
+    out = torch.empty((hi - lo, (T - 1) * 1024), device=device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.separate(wave, out=out)
+    # timed region: only the dominant kernel family (the grouped fp32-MFMA GEMM launches of the
+    # two per-band MLP chains) is bracketed with HIP events, on the launch stream
+    model.set_profiling(DOMINANT, device)
+    model.stage_times(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.separate(wave, out=out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom_stages = model.stage_times(reset=True)
+    # per-stage table: a few extra steps with every stage bracketed (not part of `value`)
+    model.set_profiling(True, device)
+    n_extra = 5
+    for _ in range(n_extra):
+        model.separate(wave, out=out)
+    stages = model.stage_times(reset=True)
+    model.set_profiling(False, device)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_total = args.rows * world * T * args.steps
+    value = frames_total / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    if rank == 0:
+        rf = (hi - lo) * T                                   # row-frames one launch processes on this GPU
+        macs = exact_macs(spec.generate_bandsplits()[0])
+        per_step = {k: (ms / n_extra) for k, (ms, n) in stages.items() if n}
+        fam = {}
+        for name, ms in per_step.items():
+            fam[name] = {"ms_per_step": round(ms, 4)}
+            if name in macs:
+                fam[name]["tflops"] = round(2 * macs[name] * rf / (ms * 1e-3) / 1e12, 2)
+        # dominant kernel = gemm_f32_kernel; its 10 launches per step inside the two MLP chains are
+        # what the timed-region events bracket (5 launches per bracket)
+        dom_ms_step = sum(dom_stages[k][0] for k in DOMINANT) / args.steps
+        dom_flop_step = 2 * sum(macs[k] for k in DOMINANT) * rf
+        n_launch = 10
+        achieved = dom_flop_step / (dom_ms_step * 1e-3) / 1e12
+        roofline = {"kernel": "gemm_f32_kernel (grouped per-band Linear layers: bandsplit_mlp + mask_mlp, %d launches/step)" % n_launch,
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom_ms_step / n_launch, 4), "launches_per_step": n_launch,
+                    "flop_per_launch_avg": dom_flop_step / n_launch,
+                    "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); flops = 2 x MACs of the Linear layers x row-frames; "
+                            "HIP events on the launch stream over the timed region"}
+        dp_ms = sum(per_step.get(k, 0.0) for k in ("band_lstm", "band_fc", "time_lstm", "time_fc"))
+        dp_gbs = BYTES_DUAL_PATH * rf / (dp_ms * 1e-3) / 1e9 if dp_ms else 0.0
+        dual = {"bound": "hbm", "achieved": round(dp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(dp_gbs / PEAK_HBM_GBS, 4), "ms_per_step": round(dp_ms, 4),
+                "tflops": round(2 * sum(macs[k] for k in ("band_lstm", "band_fc", "time_lstm", "time_fc")) * rf / (dp_ms * 1e-3) / 1e12, 2) if dp_ms else 0.0,
+                "note": "north-star accounting of the dual-path step: 24576 algorithmic B/row-frame; the step is fp32-compute/latency bound (SURVEY 7.3-1)"}
+        line = {
+            "metric": "separated row-frames/sec, batch64 8s@16kHz",
+            "value": round(value, 1), "unit": "row-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "offline separate (STFT->BSRNN.forward->iSTFT), %d rows/GPU x %d samples @16 kHz (T=%d), K=12 bands, fp32"
+                                   % (args.rows, args.samples, T),
+                       "rows_per_gpu": args.rows, "global_rows": args.rows * world, "frames": T, "parallelism": "dp%d (row shards, no in-path collective)" % world},
+            "rtf": round(elapsed / args.steps / (args.rows * args.samples / 16000.0), 8),
+            "pipeline_hbm": {"achieved_GBs": round(BYTES_PIPELINE * rf / (ms_per_step * 1e-3) / 1e9, 1), "peak_GBs": PEAK_HBM_GBS},
+            "roofline": roofline, "roofline_dual_path": dual, "stages": fam,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(sd, args.rows, args.samples)
+            line["cpu_baseline"] = cb
+            line["gpu_over_cpu"] = round(value / cb["value"], 1)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,8 +118,10 @@ int  bsrnn_stream_step_host(bsrnn_stream* s, const float* chunk_host, float* out
 int  bsrnn_stream_get_state(bsrnn_stream* s, float* state_host /* [4,2,C*K,64] */);
 
 /* ---- measurement support ---------------------------------------------------------------
- * With profiling on, every stage of a compute call is bracketed by hipEvents on the call's
- * stream; bsrnn_stage_times() synchronises on the last call and returns per-stage elapsed
+ * bsrnn_set_profiling(ctx, mask): bit i of `mask` brackets stage i of every compute call with
+ * hipEvents on the call's stream (mask < 0 = all stages, 0 = off; each bracket costs ~10 us of
+ * stream time, so time-critical runs enable only the stage they report);
+ * bsrnn_stage_times() synchronises on the last call and returns per-stage elapsed
  * milliseconds (accumulated since the last reset) and launch counts.  Stage names:
  * bsrnn_stage_name(i).  Used by bench.py for the live roofline figure. */
 int         bsrnn_set_profiling(bsrnn_ctx* ctx, int32_t on);

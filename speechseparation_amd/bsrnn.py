@@ -240,8 +240,18 @@ class BSRNN(nn.Module):
 
     # ------------------------------------------------------------------ measurement
     def set_profiling(self, on, device=None):
+        """on: False/True (all stages) or an iterable of stage names to bracket with events."""
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        _check(_lib.bsrnn_set_profiling(self._context(dev), 1 if on else 0))
+        if on is True:
+            mask = -1
+        elif not on:
+            mask = 0
+        else:
+            names = _native.stage_names()
+            mask = 0
+            for s in on:
+                mask |= 1 << names.index(s)
+        _check(_lib.bsrnn_set_profiling(self._context(dev), mask))
 
     def stage_times(self, reset=True):
         """-> {stage: (total_ms, launches)} accumulated while profiling was on."""

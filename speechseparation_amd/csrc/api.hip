@@ -5,9 +5,11 @@
 #include "../../include/bsrnn_hip.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -69,7 +71,7 @@ struct bsrnn_ctx {
     float* d_arena = nullptr;
     GemmJob* d_jobs = nullptr;
     int2* d_tiles = nullptr;
-    int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT];
+    int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT], tile_n[NSLOT];
     const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
     float* d_tables = nullptr;
     FftTables tb;
@@ -82,7 +84,7 @@ struct bsrnn_ctx {
     float* d_tap = nullptr;
 
     // profiling
-    bool prof = false;
+    unsigned prof = 0;            // bitmask of stages bracketed by events
     std::vector<EvRec> pool;
     size_t pool_used = 0;
     double acc_ms[NSTAGE];
@@ -102,7 +104,7 @@ struct StageScope {   // brackets one stage of a call with events when profiling
     bsrnn_ctx* c; hipStream_t s; EvRec* r = nullptr;
     StageScope(bsrnn_ctx* c_, int stage, hipStream_t s_) : c(c_), s(s_)
     {
-        if (c->prof && c->pool_used < c->pool.size()) {
+        if (((c->prof >> stage) & 1u) && c->pool_used < c->pool.size()) {
             r = &c->pool[c->pool_used++];
             r->stage = stage;
             (void)hipEventRecord(r->a, s);
@@ -263,6 +265,7 @@ void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ld
     g.jobs = c->d_jobs + c->job0[slot];
     g.tiles = c->d_tiles + c->tile0[slot];
     g.n_tiles = c->ntiles[slot];
+    g.tile_n = c->tile_n[slot];
     g.X = X; g.ldx = ldx; g.Y = Y; g.ldy = ldy; g.R = R; g.ldr = ldr; g.Mul = Mul; g.ldm = ldm;
     g.tap = tap; g.ldt = F2; g.M = M; g.epilogue = epi;
     launch_gemm(g, s);
@@ -470,18 +473,34 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         const Param& bi = P_(c, std::string(prefix) + ".bias");
         jw.push_back(ar.put(w.data));
         jb.push_back(ar.put(bi.data));
-        const int ji = (int)jobs.size();
         jobs.push_back(j);
-        for (int t = 0; t < (N + 63) / 64; ++t) tiles.push_back(make_int2(ji, t));
     };
     auto begin_slot = [&](int slot) { c->job0[slot] = (int)jobs.size(); c->tile0[slot] = (int)tiles.size(); };
-    auto end_slot = [&](int slot) { c->njobs[slot] = (int)jobs.size() - c->job0[slot]; c->ntiles[slot] = (int)tiles.size() - c->tile0[slot]; };
+    // column tiles of a slot: 128 wide when any layer of the slot is wider than 64 columns (the
+    // 128 x 128 kernel does twice the MFMA work per barrier), else 64; heaviest K first so the
+    // tail of a launch is made of cheap tiles.  tiles[].x is relative to the slot's first job.
+    auto end_slot = [&](int slot) {
+        const int j0 = c->job0[slot];
+        c->njobs[slot] = (int)jobs.size() - j0;
+        int maxn = 0;
+        for (int ji = j0; ji < (int)jobs.size(); ++ji) maxn = imax(maxn, jobs[ji].N);
+        // 128-wide tiles pay off only when the launch has many more workgroups than CU slots (uniform
+        // large GEMMs: 114 vs 99 TFLOP/s); at M = C*T ~ 8k rows the 64-wide tiling balances the ragged
+        // per-band costs better (measured 2.75 vs 2.79 ms per step), so it is the default.
+        const int tn = (maxn > 64 && getenv("BSRNN_GEMM_TILE128")) ? 128 : 64;
+        c->tile_n[slot] = tn;
+        std::vector<int> order;
+        for (int ji = j0; ji < (int)jobs.size(); ++ji) order.push_back(ji);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return jobs[a].K > jobs[b].K; });
+        for (int ji : order)
+            for (int t = 0; t < (jobs[ji].N + tn - 1) / tn; ++t) tiles.push_back(make_int2(ji - j0, t));
+        c->ntiles[slot] = (int)tiles.size() - c->tile0[slot];
+    };
 
     // per-band MLP chains; tiles[].x is relative to the slot's first job
     struct Def { int slot; const char* fmt; };
     for (int slot = PRE0; slot <= POST2; ++slot) {
         begin_slot(slot);
-        const int j0 = (int)jobs.size();
         for (int i = 0; i < K; ++i) {
             const int a = 2 * c->widths[i];
             const int xin = 2 * c->off[i];         // interleaved re/im column of the band
@@ -495,7 +514,6 @@ int bsrnn_commit_params(bsrnn_ctx* c)
                     const Param& cst = P_(c, b);
                     jw.push_back(ar.put(cst.data)); jb.push_back(ar.put(cst.data));
                     jobs.push_back(j);
-                    tiles.push_back(make_int2((int)jobs.size() - 1, 0));
                 }
                 continue;
             }
@@ -513,17 +531,14 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             }
         }
         end_slot(slot);
-        for (int t = c->tile0[slot]; t < (int)tiles.size(); ++t) tiles[t].x -= j0;
     }
     // fc of the four NormRNNResidual blocks (bsrnn.py:84), one job each over M*K rows
     for (int j = 0; j < 4; ++j) {
         const int slot = BLK_FC0 + j;
         begin_slot(slot);
-        const int j0 = (int)jobs.size();
         snprintf(b, sizeof b, "lstms.%d.m.fc", j);
         add_job(b, H, (j % 2 == 0) ? 2 * H : H, 0, 0, 0, 0);
         end_slot(slot);
-        for (int t = c->tile0[slot]; t < (int)tiles.size(); ++t) tiles[t].x -= j0;
     }
 
     // LSTM weights, folded and packed in the kernels' register order (lstm.hip)
@@ -843,7 +858,7 @@ int bsrnn_set_profiling(bsrnn_ctx* c, int32_t on)
         c->pool.resize(8192);
         for (auto& r : c->pool) { HIP_TRY(hipEventCreate(&r.a)); HIP_TRY(hipEventCreate(&r.b)); }
     }
-    c->prof = on != 0;
+    c->prof = on < 0 ? 0xffffffffu : (unsigned)on;   // bit i enables stage i; negative = all stages
     return 0;
 }
 int bsrnn_stage_count(void) { return NSTAGE; }

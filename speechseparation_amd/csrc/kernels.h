@@ -33,8 +33,9 @@ enum GemmEpilogue {
 
 struct GemmLaunch {
     const GemmJob* jobs;     // device array
-    const int2* tiles;       // device array [n_tiles]: (job index, n-tile index inside the job)
+    const int2* tiles;       // device array [n_tiles]: (job index, column-tile index inside the job)
     int n_tiles;
+    int tile_n;              // column-tile width of this launch: 64 or 128
     const float* X; int ldx;
     float* Y; int ldy;
     const float* R; int ldr;

@@ -157,7 +157,8 @@ void launch_band_lstm(const float* xin, float* hout, const float* wpk, const flo
 // =====================================================================================
 // Time-axis LSTM (2 layers, unidirectional, causal), state in / state out.
 // grid = ceil(R*K / 4), 512 threads: waves 0-3 run layer 0 at step s, waves 4-7 run layer 1
-// at step s-1 (software pipeline across layers), one workgroup barrier per step.
+// at step s-1 (software pipeline across layers), one workgroup barrier per step; the two groups
+// order their MFMA and cell-update phases differently so that they overlap on the shared SIMDs.
 //
 // The recurrence is latency bound (T sequential steps), so a workgroup takes only FOUR
 // sequences and the gates are computed with v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4x4,
@@ -239,56 +240,78 @@ __global__ __launch_bounds__(512) void time_lstm_kernel(const float* __restrict_
     float hsel = 0.f, csel = 0.f;
     __syncthreads();
 
+    // Gate accumulators (4 independent MFMA chains).  The two layer-groups run the same work in a
+    // different order so that one group's cell update (VALU/transcendental) overlaps the other
+    // group's MFMAs on the shared SIMD:
+    //   layer 0, iteration s:  W_h.h0_{s-1} -> cell(s) -> publish h0_s -> bias + W_x.x_{s+1} (for s+1)
+    //   layer 1, iteration s:  bias + W_x.h0_{s-1} -> W_h.h1_{s-2} -> cell(s-1) -> publish h1_{s-1}
+    // h_t of either layer lives in LDS slot t & 1; one workgroup barrier per iteration.
+    v4f a0 = {bs, bs, bs, bs}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+    auto gemv64 = [&](const float* src, const int wofs) {
+        // all 16 reads first: a 4x4x1 MFMA lasts 8 cycles, so reads trickled in between groups of
+        // four MFMAs leave the chain waiting on LDS latency (measured: MFMA pipe 33 % busy)
+        v4f av[HID / 4];
+#pragma unroll
+        for (int m = 0; m < HID / 4; ++m) av[m] = *reinterpret_cast<const v4f*>(src + 4 * m);
+        __builtin_amdgcn_sched_barrier(0);        // keep hipcc from sinking the reads back between the MFMAs
+#pragma unroll
+        for (int m = 0; m < HID / 4; ++m) {
+            a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m][0], w[wofs + 4 * m + 0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m][1], w[wofs + 4 * m + 1], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m][2], w[wofs + 4 * m + 2], a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m][3], w[wofs + 4 * m + 3], a3, 0, 0, 0);
+        }
+    };
+    auto reset_acc = [&]() {
+        a0 = (v4f){bs, bs, bs, bs};
+        a1 = a2 = a3 = (v4f){0.f, 0.f, 0.f, 0.f};
+    };
+    auto cell = [&](int t) {
+        const v4f gsum = (a0 + a1) + (a2 + a3);
+        // this lane's gate type j: tanh for g (j == 2), sigmoid otherwise; tanh(x) = 2 sigmoid(2x) - 1
+        const float sc = (j == 2) ? 2.f : 1.f;
+        float hnew[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sg = fast_sigmoid(sc * gsum[i]);
+            const float act = sc * sg - (sc - 1.f);
+            const float ig = quad_bcast<0x00>(act);
+            const float fg = quad_bcast<0x55>(act);
+            const float gg = quad_bcast<0xAA>(act);
+            const float og = quad_bcast<0xFF>(act);
+            c[i] = fg * c[i] + ig * gg;
+            hnew[i] = og * fast_tanh(c[i]);
+        }
+        hsel = j == 0 ? hnew[0] : j == 1 ? hnew[1] : j == 2 ? hnew[2] : hnew[3];
+        csel = j == 0 ? c[0] : j == 1 ? c[1] : j == 2 ? c[2] : c[3];
+        float* hb = layer ? h1buf[t & 1] : h0buf[t & 1];
+        hb[j * TS + unit] = hsel;
+        if (layer && nj_raw < N) hout[base_j + (size_t)t * tstride + unit] = hsel;
+    };
+    if (layer == 0) gemv64(&xbuf[0][0][j * TS], 0);          // input half of step 0
+
     for (int s = 0; s <= T; ++s) {
         const int chunk = s / TCH, sin = s % TCH;
         const bool have_next = (chunk + 1) * TCH < T;
         if (sin == 0 && have_next) xnext = chunk_load(chunk + 1);
 
-        const int t = layer ? s - 1 : s;                   // the time step this wave computes
-        const bool active = layer ? (s >= 1) : (s < T);
-        if (active) {
-            // A operands: layer 0: [x_t | h0_{t-1}], layer 1: [h0_t | h1_{t-1}];  h_t lives in slot t&1
-            const float* xa = layer ? &h0buf[t & 1][j * TS] : &xbuf[chunk & 1][sin][j * TS];
-            const float* ha = layer ? &h1buf[(t + 1) & 1][j * TS] : &h0buf[(t + 1) & 1][j * TS];
-            v4f a0 = {bs, bs, bs, bs}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
-#pragma unroll
-            for (int m = 0; m < HID / 4; ++m) {
-                const v4f a = *reinterpret_cast<const v4f*>(xa + 4 * m);
-                a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], w[4 * m + 0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], w[4 * m + 1], a1, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], w[4 * m + 2], a2, 0, 0, 0);
-                a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], w[4 * m + 3], a3, 0, 0, 0);
+        if (layer == 0) {
+            if (s < T) {
+                gemv64(&h0buf[(s + 1) & 1][j * TS], HID);                 // recurrent half, h0_{s-1}
+                cell(s);
+                if (s + 1 < T) {                                          // input half of step s+1
+                    reset_acc();
+                    gemv64(&xbuf[((s + 1) / TCH) & 1][(s + 1) % TCH][j * TS], 0);
+                }
             }
-#pragma unroll
-            for (int m = 0; m < HID / 4; ++m) {
-                const v4f a = *reinterpret_cast<const v4f*>(ha + 4 * m);
-                a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], w[HID + 4 * m + 0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], w[HID + 4 * m + 1], a1, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], w[HID + 4 * m + 2], a2, 0, 0, 0);
-                a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], w[HID + 4 * m + 3], a3, 0, 0, 0);
-            }
-            const v4f gsum = (a0 + a1) + (a2 + a3);
-            // this lane's gate type j: tanh for g (j == 2), sigmoid otherwise; tanh(x) = 2 sigmoid(2x) - 1
-            const float sc = (j == 2) ? 2.f : 1.f;
-            float hnew[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float sg = fast_sigmoid(sc * gsum[i]);
-                const float act = sc * sg - (sc - 1.f);
-                const float ig = quad_bcast<0x00>(act);
-                const float fg = quad_bcast<0x55>(act);
-                const float gg = quad_bcast<0xAA>(act);
-                const float og = quad_bcast<0xFF>(act);
-                c[i] = fg * c[i] + ig * gg;
-                hnew[i] = og * fast_tanh(c[i]);
-            }
-            hsel = j == 0 ? hnew[0] : j == 1 ? hnew[1] : j == 2 ? hnew[2] : hnew[3];
-            csel = j == 0 ? c[0] : j == 1 ? c[1] : j == 2 ? c[2] : c[3];
-            float* hb = layer ? h1buf[t & 1] : h0buf[t & 1];
-            hb[j * TS + unit] = hsel;
-            if (layer && nj_raw < N) hout[base_j + (size_t)t * tstride + unit] = hsel;
+        } else if (s >= 1) {
+            const int t = s - 1;
+            reset_acc();
+            gemv64(&h0buf[t & 1][j * TS], 0);                             // input half: h0_t
+            gemv64(&h1buf[(t + 1) & 1][j * TS], HID);                     // recurrent half: h1_{t-1}
+            cell(t);
         }
-        if (sin == TCH - 1 && have_next) chunk_store(chunk + 1, xnext);
+        if (sin == TCH - 2 && have_next) chunk_store(chunk + 1, xnext);
         __syncthreads();
     }
 

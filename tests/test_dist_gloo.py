@@ -1,0 +1,64 @@
+"""world_size-2 gloo test of the multi-GPU bookkeeping (CPU): row sharding, shard-exact input
+generation, output gather and the max-over-ranks timing reduce.  The per-shard work here is
+the oracle's STFT (row-wise like the real path); the HIP path itself is covered by -m gpu."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from speechseparation_amd import weights
+from speechseparation_amd.dist import gather_rows, max_over_ranks, separate_sharded, shard_rows
+
+
+def test_shard_rows_partition():
+    for total in (1, 5, 64, 512, 7):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_rows(total, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_rows(512, 8, 3) == (192, 256)          # config 4: 64 rows per GPU
+
+
+def _worker(rank, world, port, total_rows, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import bsrnn_numpy as onp
+    lo, hi = shard_rows(total_rows, world, rank)
+    wave = torch.from_numpy(weights.synth_waveform(hi - lo, n, seed=1234, row_offset=lo))   # exactly this rank's rows
+    fn = lambda w: torch.from_numpy(onp.stft_interleaved(w.numpy()))
+    lo2, hi2, out = separate_sharded(fn, torch.from_numpy(weights.synth_waveform(total_rows, n, seed=1234)), world, rank)
+    assert (lo, hi) == (lo2, hi2)
+    assert torch.equal(out, fn(wave))                    # shard generated locally == slice of the global batch
+    full = gather_rows(out, total_rows)
+    t = max_over_ranks(1.0 + rank)
+    dist.barrier()
+    if rank == 0:
+        q.put((full.numpy(), t))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_matches_unsharded():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total_rows, n = 5, 3000                              # odd row count: shards of 3 and 2
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total_rows, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full, t = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import bsrnn_numpy as onp
+    ref = onp.stft_interleaved(weights.synth_waveform(total_rows, n, seed=1234))
+    assert np.array_equal(full, ref)
+    assert t == 2.0
