@@ -28,6 +28,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BK = 32, LDS_STRIDE = 36, MCHUNK = 8;
+#ifndef GEMM_OCC64
+#define GEMM_OCC64 3          // waves per SIMD (= workgroups per CU) requested for the 64-wide kernel
+#endif
 
 // explicit global address space: pointers that are loaded from the job table would otherwise be
 // generic and compile to flat_load, which also counts in lgkmcnt and so serialises the global
@@ -40,7 +43,7 @@ typedef const v2f __attribute__((address_space(1)))* gcf2;
 // loads after the first K slab, 2 = no MFMAs, 3 = neither, +4 = no barriers / LDS writes after the
 // first slab.  PRIO: 0 none, 1 = s_setprio(1) around the MFMA cluster, 2 = static per-workgroup priority.
 template <int EPI, int NT, int ABL = 0, int PRIO = 0>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmLaunch g)
+__global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kernel(GemmLaunch g)
 {
     constexpr int BN = 64 * NT;
     constexpr int NB = 4 * NT;                 // float2 staging units per thread for the B tile

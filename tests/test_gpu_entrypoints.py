@@ -1,0 +1,184 @@
+"""GPU tests of the drop-in entry points: the LADSPA plugin driven through its C ABI exactly as
+a LADSPA host would (ctypes mirror of the public LADSPA_Descriptor), and the two command-line
+scripts.  Checked against the oracle's restatement of speech-ladspa-onnx.cpp:152-267 and of
+infer.py / infer-streaming.py."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+PLUGIN = os.path.join(REPO, "speechseparation_amd", "lib", "speech_separator_ladspa.so")
+
+
+class PortRangeHint(C.Structure):
+    _fields_ = [("HintDescriptor", C.c_int), ("LowerBound", C.c_float), ("UpperBound", C.c_float)]
+
+
+class Descriptor(C.Structure):
+    pass
+
+
+INSTANTIATE = C.CFUNCTYPE(C.c_void_p, C.POINTER(Descriptor), C.c_ulong)
+CONNECT = C.CFUNCTYPE(None, C.c_void_p, C.c_ulong, C.POINTER(C.c_float))
+VOIDH = C.CFUNCTYPE(None, C.c_void_p)
+RUN = C.CFUNCTYPE(None, C.c_void_p, C.c_ulong)
+GAIN = C.CFUNCTYPE(None, C.c_void_p, C.c_float)
+Descriptor._fields_ = [
+    ("UniqueID", C.c_ulong), ("Label", C.c_char_p), ("Properties", C.c_int), ("Name", C.c_char_p), ("Maker", C.c_char_p),
+    ("Copyright", C.c_char_p), ("PortCount", C.c_ulong), ("PortDescriptors", C.POINTER(C.c_int)),
+    ("PortNames", C.POINTER(C.c_char_p)), ("PortRangeHints", C.POINTER(PortRangeHint)), ("ImplementationData", C.c_void_p),
+    ("instantiate", INSTANTIATE), ("connect_port", CONNECT), ("activate", VOIDH), ("run", RUN), ("run_adding", RUN),
+    ("set_run_adding_gain", GAIN), ("deactivate", VOIDH), ("cleanup", VOIDH)]
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+@pytest.fixture(scope="module")
+def weight_file(tmp_path_factory, sd_default):
+    from speechseparation_amd import weights
+    p = str(tmp_path_factory.mktemp("w") / "model-always.bsrnnw")
+    weights.save_flat(p, sd_default)
+    return p
+
+
+def test_ladspa_descriptor_matches_reference():
+    lib = C.CDLL(PLUGIN)
+    lib.ladspa_descriptor.restype = C.POINTER(Descriptor)
+    lib.ladspa_descriptor.argtypes = [C.c_ulong]
+    assert not lib.ladspa_descriptor(1)
+    d = lib.ladspa_descriptor(0).contents
+    # speech-ladspa-onnx.cpp:293-337
+    assert d.UniqueID == 0xF433B044 and d.Label == b"speech_separator" and d.Name == b"Speech Separator"
+    assert d.Maker == b"Pierre-Hugues Husson @ Freebox" and d.Copyright == b"None" and d.Properties == 0 and d.PortCount == 5
+    assert [d.PortDescriptors[i] for i in range(5)] == [0x1 | 0x4, 0x1 | 0x8, 0x1 | 0x8, 0x2 | 0x8, 0x2 | 0x8]
+    assert [d.PortNames[i] for i in range(5)] == [b"Control", b"Input (Left)", b"Input (Right)", b"Output (Left)", b"Output (Right)"]
+    assert d.PortRangeHints[0].HintDescriptor == (0x240 | 0x1) and d.PortRangeHints[0].LowerBound == 0.0
+    assert not d.activate and not d.run_adding and not d.deactivate and d.run and d.cleanup
+
+
+def test_ladspa_instantiate_fails_cleanly_without_weights(tmp_path):
+    env = dict(os.environ, BSRNN_WEIGHTS=str(tmp_path / "missing.bsrnnw"))
+    code = ("import ctypes as C; l=C.CDLL(%r); l.ladspa_descriptor.restype=C.c_void_p; "
+            "import sys; sys.path.insert(0,%r); sys.path.insert(0,%r+'/tests'); from test_gpu_entrypoints import Descriptor; "
+            "d=C.cast(l.ladspa_descriptor(0), C.POINTER(Descriptor)).contents; h=d.instantiate(None, 44100); "
+            "print('HANDLE', h)") % (PLUGIN, REPO, REPO)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "HANDLE None" in out.stdout, out.stdout + out.stderr     # NULL, no crash, nothing thrown across the ABI
+
+
+@pytest.mark.parametrize("mix", [1.0, 0.35, -0.5])
+def test_ladspa_run_matches_oracle(weight_file, sd_default, mix):
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    os.environ["BSRNN_WEIGHTS"] = weight_file
+    lib = C.CDLL(PLUGIN)
+    lib.ladspa_descriptor.restype = C.POINTER(Descriptor)
+    lib.ladspa_descriptor.argtypes = [C.c_ulong]
+    d = lib.ladspa_descriptor(0).contents
+    h = d.instantiate(None, 44100)
+    assert h
+    wave = weights.synth_waveform(2, 6 * 1024, seed=77)
+    control = np.array([mix], np.float32)
+    oracle = onp.LadspaOracle(sd_default)
+    p = 0
+    outs, refs = [], []
+    for n in (333, 1024, 1, 2048, 690, 1024, 1024):          # arbitrary host block sizes, 6144 samples
+        i1 = np.ascontiguousarray(wave[0, p:p + n]); i2 = np.ascontiguousarray(wave[1, p:p + n])
+        o1 = np.empty(n, np.float32); o2 = np.empty(n, np.float32)
+        d.connect_port(h, 0, fptr(control)); d.connect_port(h, 1, fptr(i1)); d.connect_port(h, 2, fptr(i2))
+        d.connect_port(h, 3, fptr(o1)); d.connect_port(h, 4, fptr(o2))
+        d.run(h, n)
+        r1, r2 = oracle.run(i1, i2, mix)
+        assert np.array_equal(o1, o2)                        # mono result on both outputs
+        outs.append(o1); refs.append(r1)
+        p += n
+    d.cleanup(h)
+    got, ref = np.concatenate(outs), np.concatenate(refs)
+    assert np.all(got[:1024] == 0)                           # one-chunk output delay
+    err = float(np.abs(got - ref).max())
+    print("ladspa mix=%g err %.3e" % (mix, err))
+    assert err < 1e-4
+
+
+def test_ladspa_in_place_buffers(weight_file):
+    """Hosts may run in place (output buffer == input buffer); the reference reads before it writes."""
+    from speechseparation_amd import weights
+    os.environ["BSRNN_WEIGHTS"] = weight_file
+    lib = C.CDLL(PLUGIN)
+    lib.ladspa_descriptor.restype = C.POINTER(Descriptor)
+    lib.ladspa_descriptor.argtypes = [C.c_ulong]
+    d = lib.ladspa_descriptor(0).contents
+    wave = weights.synth_waveform(2, 3 * 1024, seed=5)
+    control = np.array([1.0], np.float32)
+    res = []
+    for inplace in (False, True):
+        h = d.instantiate(None, 48000)
+        a = wave[0].copy(); b = wave[1].copy()
+        o1 = a if inplace else np.empty_like(a); o2 = b if inplace else np.empty_like(b)
+        d.connect_port(h, 0, fptr(control)); d.connect_port(h, 1, fptr(a)); d.connect_port(h, 2, fptr(b))
+        d.connect_port(h, 3, fptr(o1)); d.connect_port(h, 4, fptr(o2))
+        d.run(h, a.size)
+        res.append(o1.copy())
+        d.cleanup(h)
+    assert np.array_equal(res[0], res[1])
+
+
+def _write_wav(path, wave, sr):
+    from speechseparation_amd import audio
+    audio.save_wav(path, torch.from_numpy(wave), sr)
+
+
+def test_infer_cli(tmp_path, sd_default):
+    """infer.py: same flags and output files as the reference; values against the oracle sandwich."""
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import audio, weights
+    wave = weights.synth_waveform(1, 16000 * 2 + 123, seed=9)            # mono 2 s @ 16 kHz, ragged tail
+    src, dst = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    _write_wav(src, wave, 16000)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "infer.py"), "--input", src, "--output", dst,
+                          "--synthetic-weights", "0", "--outdir", str(tmp_path)], capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode == 0, out.stderr
+    assert "Separation dB" in out.stdout
+    got, sr = audio.load_wav(dst)
+    assert sr == 16000 and got.shape[0] == 2
+    ref = onp.separate(sd_default, np.concatenate((wave, wave), 0))       # mono duplicated to two rows (infer.py:26-27)
+    assert got.shape[1] == ref.shape[1]
+    assert float(np.abs(got.numpy() - ref).max()) < 1e-4
+    for tag in ("100", "90", "50", "20", "-100"):
+        m, _ = audio.load_wav(str(tmp_path / ("mix_%s.wav" % tag)))
+        assert m.shape == got.shape and bool(torch.isfinite(m).all())
+    # the printed figure uses the natural log, as the reference does (infer.py:47)
+    w2 = np.concatenate((wave, wave), 0)[:, :ref.shape[1]]
+    expect = 10 * np.log(np.sum(w2 ** 2) / np.sum((w2 - ref) ** 2))
+    printed = float(out.stdout.split("Separation dB")[1].split()[0])
+    assert abs(printed - expect) < 1e-2
+
+
+def test_infer_streaming_cli(tmp_path, sd_default):
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import audio, weights
+    wave = weights.synth_waveform(2, 44100 // 4 + 50, seed=10)           # already 44.1 kHz: no resampling in the way
+    src, dst = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    _write_wav(src, wave, 44100)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "infer-streaming.py"), "--input", src, "--output", dst, "--name", "t",
+                          "--synthetic-weights", "0", "--export", str(tmp_path / "hello.bsrnnw")],
+                         capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode == 0, out.stderr
+    assert "Elapsed" in out.stdout and os.path.exists(str(tmp_path / "hello.bsrnnw"))
+    got, sr = audio.load_wav(dst)
+    n_chunks = wave.shape[1] // 1024
+    assert sr == 44100 and tuple(got.shape) == (2, n_chunks * 1024)
+    so = onp.StreamingOracle(sd_default, C=2)
+    ref = np.concatenate([so.step(wave[:, i * 1024:(i + 1) * 1024]) for i in range(n_chunks)], 1)
+    assert float(np.abs(got.numpy() - ref).max()) < 1e-4
+    v, sd2 = weights.load_flat(str(tmp_path / "hello.bsrnnw"))
+    assert all(np.array_equal(sd2[k], sd_default[k]) for k in sd_default)
