@@ -73,6 +73,25 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("BSRNN_CPU_THREADS", "16"))))
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE and
+    WRITE_SIZE passes with the gfx950 x2 fetch correction).  The bracketed stages launch the LEAKY
+    epilogue 8x, LINEAR 1x and MASK 1x per step."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    tot = 0.0
+    for key, n in (("gemm_f32_kernel<1,", 8), ("gemm_f32_kernel<0,", 1), ("gemm_f32_kernel<3,", 1)):
+        hit = [v for k, v in d.items() if k.startswith(key)]
+        if not hit:
+            return None, None
+        tot += n * (hit[0]["fetched_bytes"] + hit[0]["written_bytes"])
+    return tot / 10.0, os.path.basename(files[-1])
+
+
 def build_model(device):
     from speechseparation_amd import weights
     from speechseparation_amd.bsrnn import BSRNN
@@ -183,11 +202,12 @@ def main():
         dom_ms_step = sum(dom_stages[k][0] for k in DOMINANT) / args.steps
         dom_flop_step = 2 * sum(macs[k] for k in DOMINANT) * rf
         n_launch = 10
+        traffic, traffic_src = profiled_traffic()
         achieved = dom_flop_step / (dom_ms_step * 1e-3) / 1e12
         roofline = {"kernel": "gemm_f32_kernel (grouped per-band Linear layers: bandsplit_mlp + mask_mlp, %d launches/step)" % n_launch,
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(dom_ms_step / n_launch, 4), "launches_per_step": n_launch,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms_step / n_launch, 4), "launches_per_step": n_launch,
                     "flop_per_launch_avg": dom_flop_step / n_launch,
                     "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); flops = 2 x MACs of the Linear layers x row-frames; "
                             "HIP events on the launch stream over the timed region"}
