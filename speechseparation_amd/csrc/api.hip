@@ -72,8 +72,10 @@ struct bsrnn_ctx {
     GemmJob* d_jobs = nullptr;
     int2* d_tiles = nullptr;
     int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT], tile_n[NSLOT];
+
     const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
     float* d_tables = nullptr;
+    int* d_colmap = nullptr;
     FftTables tb;
 
     // workspace (grow-only)
@@ -90,7 +92,14 @@ struct bsrnn_ctx {
     double acc_ms[NSTAGE];
     int64_t acc_n[NSTAGE];
     hipStream_t last_stream = nullptr;
+
+    // concurrent row blocks of one call (bsrnn_separate)
+    int n_parts = 1, part_lag = 0;     // BSRNN_PARTS / BSRNN_PART_LAG; measured at R=64: 2 parts = +1.8 %, more = worse
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
 };
+
+constexpr int MAX_PARTS = 4;
 
 struct bsrnn_stream {
     bsrnn_ctx* ctx;
@@ -237,11 +246,14 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
     if (c->d_ws) { HIP_TRY(hipFree(c->d_ws)); c->d_ws = nullptr; c->cap_rows = 0; }
     const size_t KH = (size_t)c->K * HID;
     auto seg = [](size_t n) { return (n + 63) & ~size_t(63); };
-    const size_t sizes[11] = {seg(rows * F2), seg(rows * F2), seg(rows * c->LDA), seg(rows * c->LDA), seg(rows * c->LDP),
+    const size_t sizes[11] = {seg(rows * c->LDP), seg(rows * c->LDP), seg(rows * c->LDA), seg(rows * c->LDA), seg(rows * c->LDP),
                               seg(rows * KH), seg(rows * KH), seg(rows * KH * 2), seg(rows * KH * 2), seg(rows * KH), seg(rows * NFFT)};
     size_t total = 0;
     for (size_t s : sizes) total += s;
     HIP_TRY(hipMalloc((void**)&c->d_ws, total * sizeof(float)));
+    // pad columns (band segments are 16-byte aligned, rows padded) are read as K-padding by the GEMM and are
+    // never written afterwards: they must be finite, so the whole workspace starts at zero
+    HIP_TRY(hipMemset(c->d_ws, 0, total * sizeof(float)));
     float* p = c->d_ws;
     float** dst[11] = {&c->Xf, &c->Yf, &c->A1, &c->A2, &c->P, &c->Z0, &c->Z1, &c->HB0, &c->HB1, &c->H1, &c->frames};
     for (int i = 0; i < 11; ++i) { *dst[i] = p; p += sizes[i]; }
@@ -253,8 +265,18 @@ int ensure_tap(bsrnn_ctx* c, size_t rows)
     if (rows <= c->tap_rows) return 0;
     HIP_TRY(hipDeviceSynchronize());
     if (c->d_tap) { HIP_TRY(hipFree(c->d_tap)); c->d_tap = nullptr; }
-    HIP_TRY(hipMalloc((void**)&c->d_tap, rows * F2 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->d_tap, rows * c->LDP * sizeof(float)));
     c->tap_rows = rows;
+    return 0;
+}
+
+int ensure_streams(bsrnn_ctx* c, int parts)
+{
+    if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int j = 0; j < parts; ++j) {
+        if (!c->aux[j]) HIP_TRY(hipStreamCreateWithFlags(&c->aux[j], hipStreamNonBlocking));
+        if (!c->ev_join[j]) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[j], hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -267,53 +289,112 @@ void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ld
     g.n_tiles = c->ntiles[slot];
     g.tile_n = c->tile_n[slot];
     g.X = X; g.ldx = ldx; g.Y = Y; g.ldy = ldy; g.R = R; g.ldr = ldr; g.Mul = Mul; g.ldm = ldm;
-    g.tap = tap; g.ldt = F2; g.M = M; g.epilogue = epi;
+    g.tap = tap; g.ldt = c->LDP; g.M = M; g.epilogue = epi;
     launch_gemm(g, s);
 }
 
-// The model proper on frame-major rows: Xf [M][2050] -> Yf [M][2050], M = C*T, row = c*T + t.
+// A contiguous block of rows (utterance-channels) of one call, with its slice of the workspace
+// and the stream it runs on.  Rows are independent (bsrnn.py:394-395), so a call can be cut into
+// several such parts that run concurrently on separate HIP streams.
+struct Part {
+    int C, T;                       // rows and frames of this part
+    hipStream_t s;
+    const float* Xf; float* Yf; float* tap;              // [C*T][LDP], band-padded spectrum layout
+    float *A1, *A2, *P, *Z0, *Z1, *HB0, *HB1, *H1, *frames;
+    const float* state_in; float* state_out;             // [4][2][C_total*K][64] slabs already offset to this part's first row
+    size_t state_slab;                                   // floats between the two Time blocks' slabs (uses C_total)
+    const float* wave; float* wave_out; int64_t n;       // only for the fused sandwich
+};
+
+Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s)
+{
+    Part p;
+    memset(&p, 0, sizeof p);
+    const size_t m0 = (size_t)row0 * T, KH = (size_t)c->K * HID;
+    p.C = C; p.T = T; p.s = s;
+    p.Xf = c->Xf + m0 * c->LDP; p.Yf = c->Yf + m0 * c->LDP;
+    p.A1 = c->A1 + m0 * c->LDA; p.A2 = c->A2 + m0 * c->LDA; p.P = c->P + m0 * c->LDP;
+    p.Z0 = c->Z0 + m0 * KH; p.Z1 = c->Z1 + m0 * KH; p.H1 = c->H1 + m0 * KH;
+    p.HB0 = c->HB0 + m0 * KH * 2; p.HB1 = c->HB1 + m0 * KH * 2;
+    p.frames = c->frames + m0 * NFFT;
+    return p;
+}
+
+enum { MS_STFT, MS_BANDSPLIT, MS_BAND0, MS_BANDFC0, MS_TIME0, MS_TIMEFC0, MS_BAND1, MS_BANDFC1, MS_TIME1, MS_TIMEFC1, MS_MASK, MS_ISTFT, MS_COUNT };
+
+// One stage of the model for one part.  Xf [M][2050] -> Yf [M][2050], M = C*T, row = c*T + t.
+void run_stage(bsrnn_ctx* c, const Part& p, int stage)
+{
+    const int M = p.C * p.T, K = c->K, KH = K * HID;
+    hipStream_t s = p.s;
+    switch (stage) {
+    case MS_STFT:
+        if (p.wave) { StageScope sc(c, ST_STFT, s); launch_stft(c->tb, p.wave, const_cast<float*>(p.Xf), p.C, p.n, p.T, s); }
+        break;
+    case MS_BANDSPLIT: {   // bandFCs_pre (2 linears) -> residual P; bandFCs (3 linears) -> Z0   bsrnn.py:404-415
+        StageScope sc(c, ST_BANDSPLIT, s);
+        gemm_slot(c, PRE0, p.Xf, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, PRE2, p.A1, c->LDA, p.P, c->LDP, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC0, p.P, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC4, p.A2, c->LDA, p.Z0, KH, nullptr, 0, nullptr, 0, nullptr, M, EPI_LINEAR, s);
+        break;
+    }
+    case MS_BAND0: case MS_BAND1: {   // BandwiseLSTM: N = M sequences of length K   bsrnn.py:138-153
+        const int blk = stage == MS_BAND1;
+        StageScope sc(c, ST_BAND_LSTM, s);
+        launch_band_lstm(p.Z0, p.HB0, c->bandW[blk][0], c->bandB[blk][0], M, K, 64, s);
+        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandB[blk][1], M, K, 128, s);
+        break;
+    }
+    case MS_BANDFC0: case MS_BANDFC1: {
+        const int blk = stage == MS_BANDFC1;
+        StageScope sc(c, ST_BAND_FC, s);
+        gemm_slot(c, BLK_FC0 + 2 * blk, p.HB1, 2 * HID, p.Z1, HID, p.Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+        break;
+    }
+    case MS_TIME0: case MS_TIME1: {   // TimewiseLSTM: N = C*K sequences of length T, causal, state carry   bsrnn.py:106-128
+        const int blk = stage == MS_TIME1;
+        StageScope sc(c, ST_TIME_LSTM, s);
+        launch_time_lstm(p.Z1, p.H1, c->timeW[blk], c->timeB[blk],
+                         p.state_in ? p.state_in + blk * p.state_slab : nullptr,
+                         p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, s);
+        break;
+    }
+    case MS_TIMEFC0: case MS_TIMEFC1: {
+        const int blk = stage == MS_TIMEFC1;
+        StageScope sc(c, ST_TIME_FC, s);
+        gemm_slot(c, BLK_FC1 + 2 * blk, p.H1, HID, p.Z0, HID, p.Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+        break;
+    }
+    case MS_MASK: {   // bandFCs_back (3) + bandFCs_back_post (2) + skip + x*mask   bsrnn.py:420-443
+        StageScope sc(c, ST_MASK, s);
+        gemm_slot(c, BACK0, p.Z0, KH, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, BACK2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, BACK4, p.A2, c->LDA, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, POST0, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, POST2, p.A2, c->LDA, p.Yf, c->LDP, p.P, c->LDP, p.Xf, c->LDP, p.tap, M, EPI_MASK, s);
+        break;
+    }
+    case MS_ISTFT:
+        if (p.wave_out) {
+            StageScope sc(c, ST_ISTFT, s);
+            launch_istft_frames(c->tb, p.Yf, p.frames, M, s);
+            launch_istft_ola(c->tb, p.frames, p.wave_out, p.C, p.T, s);
+        }
+        break;
+    }
+}
+
+// The model proper for a single part on one stream.
 int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T,
               const float* state_in, float* state_out, hipStream_t s)
 {
-    const int M = C * T, K = c->K, KH = K * HID;
-    {   // BandSplit: bandFCs_pre (2 linears) -> residual P; bandFCs (3 linears) -> Z0   bsrnn.py:404-415
-        StageScope sc(c, ST_BANDSPLIT, s);
-        gemm_slot(c, PRE0, Xf, F2, c->A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, PRE2, c->A1, c->LDA, c->P, c->LDP, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, FC0, c->P, c->LDP, c->A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, FC2, c->A1, c->LDA, c->A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, FC4, c->A2, c->LDA, c->Z0, KH, nullptr, 0, nullptr, 0, nullptr, M, EPI_LINEAR, s);
-    }
-    const size_t slab = (size_t)2 * 2 * C * K * HID;     // one Time block's (h,c) x 2 layers
-    for (int blk = 0; blk < 2; ++blk) {
-        {   // BandwiseLSTM: N = M sequences of length K   bsrnn.py:138-153
-            StageScope sc(c, ST_BAND_LSTM, s);
-            launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandB[blk][0], M, K, 64, s);
-            launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandB[blk][1], M, K, 128, s);
-        }
-        {
-            StageScope sc(c, ST_BAND_FC, s);
-            gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
-        }
-        {   // TimewiseLSTM: N = C*K sequences of length T, causal, state carry   bsrnn.py:106-128
-            StageScope sc(c, ST_TIME_LSTM, s);
-            launch_time_lstm(c->Z1, c->H1, c->timeW[blk], c->timeB[blk],
-                             state_in ? state_in + blk * slab : nullptr, state_out ? state_out + blk * slab : nullptr,
-                             C, T, K, s);
-        }
-        {
-            StageScope sc(c, ST_TIME_FC, s);
-            gemm_slot(c, BLK_FC1 + 2 * blk, c->H1, HID, c->Z0, HID, c->Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
-        }
-    }
-    {   // MaskEstimation: bandFCs_back (3) + bandFCs_back_post (2) + skip + x*mask   bsrnn.py:420-443
-        StageScope sc(c, ST_MASK, s);
-        gemm_slot(c, BACK0, c->Z0, KH, c->A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, BACK2, c->A1, c->LDA, c->A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, BACK4, c->A2, c->LDA, c->A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, POST0, c->A1, c->LDA, c->A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, POST2, c->A2, c->LDA, Yf, F2, c->P, c->LDP, Xf, F2, tap, M, EPI_MASK, s);
-    }
+    Part p = make_part(c, 0, C, T, s);
+    p.Xf = Xf; p.Yf = Yf; p.tap = tap;
+    p.state_in = state_in; p.state_out = state_out;
+    p.state_slab = (size_t)2 * 2 * C * c->K * HID;     // one Time block's (h,c) x 2 layers
+    for (int st = MS_BANDSPLIT; st <= MS_MASK; ++st) run_stage(c, p, st);
     c->last_stream = s;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -360,6 +441,8 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
     }
     c->LDA = ao; c->LDP = imax(po, 4);
     build_inventory(c);
+    if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(1, std::min(MAX_PARTS, atoi(e)));
+    if (const char* e = getenv("BSRNN_PART_LAG")) c->part_lag = std::max(0, std::min((int)MS_COUNT, atoi(e)));
     memset(c->acc_ms, 0, sizeof c->acc_ms);
     memset(c->acc_n, 0, sizeof c->acc_n);
 
@@ -390,6 +473,16 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
     c->tb.hann = c->d_tables + o_hann;
     c->tb.inv_env = c->d_tables + o_env;
     c->tb.inv_wsum = c->d_tables + o_ws;
+    {   // bin -> column of its real part in the band-padded spectrum layout
+        std::vector<int> cm(NBINS);
+        for (int i = 0; i < n_bands; ++i)
+            for (int k = 0; k < widths[i]; ++k) cm[c->off[i] + k] = c->poff[i] + 2 * k;
+        e = hipMalloc((void**)&c->d_colmap, NBINS * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(c->d_colmap, cm.data(), NBINS * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { delete c; return fail(BSRNN_EHIP, "table upload: %s", hipGetErrorString(e)); }
+        c->tb.colmap = c->d_colmap;
+        c->tb.ld = c->LDP;
+    }
     *out = c;
     return 0;
 }
@@ -400,12 +493,18 @@ void bsrnn_destroy(bsrnn_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& r : c->pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (int j = 0; j < MAX_PARTS; ++j) {
+        if (c->aux[j]) (void)hipStreamDestroy(c->aux[j]);
+        if (c->ev_join[j]) (void)hipEventDestroy(c->ev_join[j]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_tap) (void)hipFree(c->d_tap);
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_colmap) (void)hipFree(c->d_colmap);
     delete c;
 }
 
@@ -471,7 +570,13 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         j.N = N; j.K = Kd; j.x_off = x_off; j.y_off = y_off; j.r_off = r_off; j.m_off = m_off;
         const Param& w = P_(c, std::string(prefix) + ".weight");
         const Param& bi = P_(c, std::string(prefix) + ".bias");
-        jw.push_back(ar.put(w.data));
+        // weight rows padded with zeros to a multiple of 4 floats: every row is 16-byte aligned and the kernel's
+        // K loop runs over whole float4 units (the matching input pad columns are finite, see ensure_ws)
+        const int Kp = round4(Kd);
+        j.K = Kp;
+        std::vector<float> wp((size_t)N * Kp, 0.f);
+        for (int r = 0; r < N; ++r) memcpy(&wp[(size_t)r * Kp], &w.data[(size_t)r * Kd], Kd * sizeof(float));
+        jw.push_back(ar.put(wp));
         jb.push_back(ar.put(bi.data));
         jobs.push_back(j);
     };
@@ -503,7 +608,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         begin_slot(slot);
         for (int i = 0; i < K; ++i) {
             const int a = 2 * c->widths[i];
-            const int xin = 2 * c->off[i];         // interleaved re/im column of the band
+            const int xin = c->poff[i];            // column of the band in the band-padded spectrum layout (16-byte aligned)
             const int m = imax(a, H), pz = imax(a, 2 * H);
             if (a == 0) {
                 if (slot == FC4) {                 // TrainableConstantModule -> Z[:, :, i, :] = constant
@@ -651,12 +756,12 @@ int bsrnn_forward(bsrnn_ctx* c, const float* x, float* y, float* mask, int32_t C
     const size_t M = (size_t)C * T;
     if ((rc = ensure_ws(c, M))) return rc;
     if (mask && (rc = ensure_tap(c, M))) return rc;
-    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(x, c->Xf, C, T, s); }
+    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, T, s); }
     if ((rc = run_model(c, c->Xf, c->Yf, mask ? c->d_tap : nullptr, C, T, nullptr, nullptr, s))) return rc;
     {
         StageScope sc(c, ST_LAYOUT, s);
-        launch_from_frame_major(c->Yf, y, C, T, s);
-        if (mask) launch_from_frame_major(c->d_tap, mask, C, T, s);
+        launch_from_frame_major(c->tb, c->Yf, y, C, T, s);
+        if (mask) launch_from_frame_major(c->tb, c->d_tap, mask, C, T, s);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -671,12 +776,9 @@ int bsrnn_forward_chunk(bsrnn_ctx* c, const float* x, const float* state_in, flo
     hipStream_t s = (hipStream_t)stream;
     const size_t M = (size_t)C * L;
     if ((rc = ensure_ws(c, M))) return rc;
-    if (L == 1) {       // [C,2050] is already frame-major
-        return run_model(c, x, y, nullptr, C, 1, state_in, state_out, s);
-    }
-    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(x, c->Xf, C, L, s); }
+    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, L, s); }
     if ((rc = run_model(c, c->Xf, c->Yf, nullptr, C, L, state_in, state_out, s))) return rc;
-    { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->Yf, y, C, L, s); }
+    { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->tb, c->Yf, y, C, L, s); }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -723,7 +825,7 @@ int bsrnn_stft(bsrnn_ctx* c, const float* wave, float* x, int32_t R, int64_t n, 
     int rc = ensure_ws(c, (size_t)R * T);
     if (rc) return rc;
     { StageScope sc(c, ST_STFT, s); launch_stft(c->tb, wave, c->Xf, R, n, T, s); }
-    { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->Xf, x, R, T, s); }
+    { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->tb, c->Xf, x, R, T, s); }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -736,7 +838,7 @@ int bsrnn_istft(bsrnn_ctx* c, const float* y, float* wave_out, int32_t R, int32_
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_ws(c, (size_t)R * T);
     if (rc) return rc;
-    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(y, c->Yf, R, T, s); }
+    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, y, c->Yf, R, T, s); }
     {
         StageScope sc(c, ST_ISTFT, s);
         launch_istft_frames(c->tb, c->Yf, c->frames, R * T, s);
@@ -754,13 +856,38 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
     hipStream_t s = (hipStream_t)stream;
     const int T = 1 + (int)(n / HOPS);
     if ((rc = ensure_ws(c, (size_t)R * T))) return rc;
-    { StageScope sc(c, ST_STFT, s); launch_stft(c->tb, wave, c->Xf, R, n, T, s); }
-    if ((rc = run_model(c, c->Xf, c->Yf, nullptr, R, T, nullptr, nullptr, s))) return rc;
-    {
-        StageScope sc(c, ST_ISTFT, s);
-        launch_istft_frames(c->tb, c->Yf, c->frames, R * T, s);
-        launch_istft_ola(c->tb, c->frames, wave_out, R, T, s);
+    const int64_t out_len = (int64_t)(T - 1) * HOPS;
+
+    // Rows are independent, so the batch is cut into `parts` contiguous row blocks that run the whole
+    // stage sequence concurrently on separate streams: the ramps, tails and latency-bound stages of
+    // one block (e.g. the time-axis LSTM occupies 192 of 256 CUs) overlap matrix work of the other.
+    // Part j starts `lag` stages behind part j-1 so that they sit in different stages.
+    int parts = c->n_parts;
+    if (R < 2 * parts || (int64_t)R * T < 2048) parts = 1;
+    if (parts > 1 && (rc = ensure_streams(c, parts))) return rc;
+    Part pt[MAX_PARTS];
+    for (int j = 0; j < parts; ++j) {
+        const int r0 = (int)((int64_t)R * j / parts), r1 = (int)((int64_t)R * (j + 1) / parts);
+        pt[j] = make_part(c, r0, r1 - r0, T, parts > 1 ? c->aux[j] : s);
+        pt[j].wave = wave + (size_t)r0 * n; pt[j].n = n;
+        pt[j].wave_out = wave_out + (size_t)r0 * out_len;
     }
+    if (parts > 1) {
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        for (int j = 0; j < parts; ++j) HIP_TRY(hipStreamWaitEvent(c->aux[j], c->ev_fork, 0));
+    }
+    const int lag = c->part_lag;
+    for (int step = 0; step < MS_COUNT + lag * (parts - 1); ++step)
+        for (int j = 0; j < parts; ++j) {
+            const int st = step - lag * j;
+            if (st >= 0 && st < MS_COUNT) run_stage(c, pt[j], st);
+        }
+    if (parts > 1)
+        for (int j = 0; j < parts; ++j) {
+            HIP_TRY(hipEventRecord(c->ev_join[j], c->aux[j]));
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_join[j], 0));
+        }
+    c->last_stream = s;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -774,14 +901,14 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     bsrnn_stream* st = new bsrnn_stream();
     st->ctx = c; st->C = C;
     const size_t nstate = (size_t)4 * 2 * C * c->K * HID;
-    const size_t total = (size_t)C * (NFFT * 2 + F2 * 2 + HOPS * 2) + nstate;
+    const size_t total = (size_t)C * (NFFT * 2 + (size_t)c->LDP * 2 + HOPS * 2) + nstate;
     float* p = nullptr;
     hipError_t e = hipMalloc((void**)&p, total * sizeof(float));
     if (e != hipSuccess) { delete st; return fail(BSRNN_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
     st->buf = p; p += (size_t)C * NFFT;
     st->prev = p; p += (size_t)C * NFFT;
-    st->X = p; p += (size_t)C * F2;
-    st->Y = p; p += (size_t)C * F2;
+    st->X = p; p += (size_t)C * c->LDP;
+    st->Y = p; p += (size_t)C * c->LDP;
     st->chunk = p; p += (size_t)C * HOPS;
     st->out = p; p += (size_t)C * HOPS;
     st->state = p;
@@ -807,7 +934,7 @@ int bsrnn_stream_reset(bsrnn_stream* st, void* stream)
     if (!st) return fail(BSRNN_EARG, "null stream");
     HIP_TRY(hipSetDevice(st->ctx->device));
     const size_t nstate = (size_t)4 * 2 * st->C * st->ctx->K * HID;
-    const size_t total = (size_t)st->C * (NFFT * 2 + F2 * 2 + HOPS * 2) + nstate;
+    const size_t total = (size_t)st->C * (NFFT * 2 + (size_t)st->ctx->LDP * 2 + HOPS * 2) + nstate;
     HIP_TRY(hipMemsetAsync(st->buf, 0, total * sizeof(float), (hipStream_t)stream));
     return 0;
 }

@@ -47,7 +47,7 @@ __device__ __forceinline__ float2* fft1024(float2* z0, float2* z1, const float2*
 
 // real spectrum X[0..1024] from Z = FFT1024(x[2n] + i x[2n+1]); writes interleaved re/im
 __device__ __forceinline__ void rfft_split_store(const float2* Z, const float2* __restrict__ tw2048,
-                                                 float* __restrict__ out, int tid)
+                                                 float* __restrict__ out, const int* __restrict__ colmap, int tid)
 {
     for (int k = tid; k <= 1024; k += 256) {
         const float2 zk = Z[k & 1023];
@@ -57,17 +57,18 @@ __device__ __forceinline__ void rfft_split_store(const float2* Z, const float2* 
         const float2 o = make_float2(0.5f * dd.y, -0.5f * dd.x);
         float2 x = cadd(e, cmul(tw2048[k], o));
         if (k == 0 || k == 1024) x.y = 0.f;                           // exactly real for real input
-        *reinterpret_cast<float2*>(out + 2 * k) = x;
+        *reinterpret_cast<float2*>(out + colmap[k]) = x;
     }
 }
 
 // Z[k] = E[k] + i O[k] for the inverse; imaginary parts of DC / Nyquist are ignored like c2r does
+// colmap == nullptr: Y is a plain interleaved [2050] row
 __device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const float2* __restrict__ tw2048,
-                                            float2* z, int tid)
+                                            float2* z, const int* __restrict__ colmap, int tid)
 {
     for (int k = tid; k < 1024; k += 256) {
-        float2 xk = *reinterpret_cast<const float2*>(Y + 2 * k);
-        float2 xc = *reinterpret_cast<const float2*>(Y + 2 * (1024 - k));
+        float2 xk = *reinterpret_cast<const float2*>(Y + (colmap ? colmap[k] : 2 * k));
+        float2 xc = *reinterpret_cast<const float2*>(Y + (colmap ? colmap[1024 - k] : 2 * (1024 - k)));
         if (k == 0) { xk.y = 0.f; xc.y = 0.f; }
         xc = cconj(xc);
         const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
     }
     __syncthreads();
     const float2* Z = fft1024<false>(z0, z1, tb.tw1024, tid);
-    rfft_split_store(Z, tb.tw2048, X + (size_t)m * F2, tid);
+    rfft_split_store(Z, tb.tw2048, X + (size_t)m * tb.ld, tb.colmap, tid);
 }
 
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s)
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(FftTables tb, const f
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
     const size_t m = blockIdx.x;
-    irfft_merge(Y + m * F2, tb.tw2048, z0, tid);
+    irfft_merge(Y + m * tb.ld, tb.tw2048, z0, tb.colmap, tid);
     __syncthreads();
     const float2* z = fft1024<true>(z0, z1, tb.tw1024, tid);
     float* dst = frames + m * NFFT;
@@ -159,36 +160,53 @@ void launch_istft_ola(const FftTables& tb, const float* frames, float* out, int 
     hipLaunchKernelGGL(istft_ola_kernel, grid, dim3(256), 0, s, tb, frames, out, T);
 }
 
-// ------------------------------------------------------------------------------ [C][2050][T] <-> [C*T][2050]
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols)
+// ------------------------------------------------------------------------------ [C][2050][T] <-> [C*T][ld]
+// The reference boundary is [C][2050][T] (T innermost, bsrnn.py:385); inside the library rows are
+// frames and columns follow the band-padded map.  32x32 tiles through LDS, both sides coalesced.
+template <bool TO_FRAME_MAJOR>
+__global__ __launch_bounds__(256) void layout_kernel(FftTables tb, const float* __restrict__ src, float* __restrict__ dst, int T)
 {
-    // src [batch][rows][cols] -> dst [batch][cols][rows]
     __shared__ float tile[32][33];
-    const size_t boff = (size_t)blockIdx.z * rows * cols;
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c = blockIdx.z;
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;      // f = interleaved column 0..2049
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
+    const float* ref = TO_FRAME_MAJOR ? src : nullptr;
+    if (TO_FRAME_MAJOR) {
 #pragma unroll
-    for (int i = 0; i < 32; i += 8) {
-        const int r = r0 + ty + i, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + i][tx] = src[boff + (size_t)r * cols + c];
-    }
-    __syncthreads();
+        for (int i = 0; i < 32; i += 8) {                      // read [f][t], t contiguous
+            const int f = f0 + ty + i, t = t0 + tx;
+            if (f < F2 && t < T) tile[ty + i][tx] = ref[((size_t)c * F2 + f) * T + t];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 32; i += 8) {
-        const int c = c0 + ty + i, r = r0 + tx;
-        if (r < rows && c < cols) dst[boff + (size_t)c * rows + r] = tile[tx][ty + i];
+        for (int i = 0; i < 32; i += 8) {                      // write [t][col(f)], f contiguous
+            const int t = t0 + ty + i, f = f0 + tx;
+            if (f < F2 && t < T) dst[((size_t)c * T + t) * tb.ld + tb.colmap[f >> 1] + (f & 1)] = tile[tx][ty + i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; i += 8) {                      // read [t][col(f)]
+            const int t = t0 + ty + i, f = f0 + tx;
+            if (f < F2 && t < T) tile[ty + i][tx] = src[((size_t)c * T + t) * tb.ld + tb.colmap[f >> 1] + (f & 1)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 32; i += 8) {                      // write [f][t]
+            const int f = f0 + ty + i, t = t0 + tx;
+            if (f < F2 && t < T) dst[((size_t)c * F2 + f) * T + t] = tile[tx][ty + i];
+        }
     }
 }
 
-void launch_to_frame_major(const float* x, float* xf, int C, int T, hipStream_t s)
+void launch_to_frame_major(const FftTables& tb, const float* x, float* xf, int C, int T, hipStream_t s)
 {
     dim3 grid((T + 31) / 32, (F2 + 31) / 32, C);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, x, xf, F2, T);
+    hipLaunchKernelGGL(layout_kernel<true>, grid, dim3(256), 0, s, tb, x, xf, T);
 }
-void launch_from_frame_major(const float* yf, float* y, int C, int T, hipStream_t s)
+void launch_from_frame_major(const FftTables& tb, const float* yf, float* y, int C, int T, hipStream_t s)
 {
-    dim3 grid((F2 + 31) / 32, (T + 31) / 32, C);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, yf, y, T, F2);
+    dim3 grid((T + 31) / 32, (F2 + 31) / 32, C);
+    hipLaunchKernelGGL(layout_kernel<false>, grid, dim3(256), 0, s, tb, yf, y, T);
 }
 
 // ------------------------------------------------------------------------------ streaming DSP
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, floa
     }
     __syncthreads();
     const float2* Z = fft1024<false>(z0, z1, tb.tw1024, tid);
-    rfft_split_store(Z, tb.tw2048, X + (size_t)c * F2, tid);
+    rfft_split_store(Z, tb.tw2048, X + (size_t)c * tb.ld, tb.colmap, tid);
 }
 
 __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, const float* __restrict__ Y, const float* __restrict__ X,
@@ -229,13 +247,16 @@ __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, con
     __shared__ __attribute__((aligned(16))) float spec[F2 + 2];
     const int tid = threadIdx.x;
     const int c = blockIdx.x;
-    const float* y = Y + (size_t)c * F2;
-    const float* x = X + (size_t)c * F2;
+    const float* y = Y + (size_t)c * tb.ld;
+    const float* x = X + (size_t)c * tb.ld;
     // wet/dry on the spectrum (speech-ladspa-onnx.cpp:215-226); mix = 1 is the plain model output
     const float dry = mix >= 0.f ? 1.f - mix : 1.f;
-    for (int i = tid; i < F2; i += 256) spec[i] = (mix == 1.f) ? y[i] : mix * y[i] + dry * x[i];
+    for (int i = tid; i < F2; i += 256) {
+        const int col = tb.colmap[i >> 1] + (i & 1);
+        spec[i] = (mix == 1.f) ? y[col] : mix * y[col] + dry * x[col];
+    }
     __syncthreads();
-    irfft_merge(spec, tb.tw2048, z0, tid);
+    irfft_merge(spec, tb.tw2048, z0, nullptr, tid);
     __syncthreads();
     const float2* z = fft1024<true>(z0, z1, tb.tw1024, tid);
     float* pv = prev + (size_t)c * NFFT;

@@ -9,16 +9,16 @@
 // would be 16x faster and ~1e-2 wrong.  Roofline for this kernel is therefore the fp32
 // matrix peak (157.3 TFLOP/s), see DESIGN.md.
 //
-// Tile: 128 x (64*NT) x 32 per 256-thread workgroup, four waves as 2(M) x 2(N), each wave a
+// Tile: 128 x (64*NT) x BK per 256-thread workgroup, four waves as 2(M) x 2(N), each wave a
 // 64 x (32*NT) patch = 2*NT accumulators of 32x32.  NT = 2 (128-wide) is used for the slots whose
 // layers are wide: twice the MFMA work per barrier pair and per LDS byte (measured: the NT = 1
 // structure tops out at ~66 % of peak even with global loads removed).  NT = 1 serves the
 // 64-column layers.  Operands are K-contiguous in memory for both X [M][ldx] and W [N][K], so A
-// and B fragments are read with the same pattern: lane l owns row (l & 31) and the 16-float
-// half (l >> 5) of the 32-deep K slab, fetched as four ds_read_b128; MFMA step (j, e) consumes
-// element e of the j-th read, i.e. k = 16*(l>>5) + 4j + e on BOTH operands (the sum over k is
-// order-agnostic as long as A and B agree).  LDS rows are padded to 36 floats: 36/4 = 9 is
-// odd, so the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte slots.
+// and B fragments are read with the same pattern: lane l owns row (l & 31) and the half (l >> 5)
+// of the BK-deep K slab, fetched as BK/8 ds_read_b128; MFMA step (j, e) consumes element e of the
+// j-th read, i.e. k = (BK/2)*(l>>5) + 4j + e on BOTH operands (the sum over k is order-agnostic as
+// long as A and B agree).  LDS rows are padded to BK+4 floats: (BK+4)/4 is odd, so the 16 rows of
+// a ds_read_b128 lane group hit 16 distinct 16-byte slots.
 #include "kernels.h"
 
 namespace bsrnn {
@@ -27,7 +27,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BK = 32, LDS_STRIDE = 36, MCHUNK = 8;
+#ifndef GEMM_BK
+#define GEMM_BK 32
+#endif
+constexpr int BM = 128, BK = GEMM_BK, LDS_STRIDE = BK + 4, MCHUNK_MAX = 8;
+// m-tiles per XCD-pinned chunk: 8 when there are enough m-tiles, fewer for small batches so that all
+// eight XCDs still get work (with 32 m-tiles, chunks of 8 would leave half of the chip idle)
+static inline int gemm_mchunk(int m_tiles) { const int c = (m_tiles + 7) / 8; return c < 1 ? 1 : (c > MCHUNK_MAX ? MCHUNK_MAX : c); }
+static_assert(BK == 32 || BK == 64, "BK");
 #ifndef GEMM_OCC64
 #define GEMM_OCC64 3          // waves per SIMD (= workgroups per CU) requested for the 64-wide kernel
 #endif
@@ -42,16 +49,20 @@ typedef const v2f __attribute__((address_space(1)))* gcf2;
 // ABL is a measurement-only switch (tools/gemm_bench.hip): 0 = the product kernel, 1 = no global
 // loads after the first K slab, 2 = no MFMAs, 3 = neither, +4 = no barriers / LDS writes after the
 // first slab.  PRIO: 0 none, 1 = s_setprio(1) around the MFMA cluster, 2 = static per-workgroup priority.
-template <int EPI, int NT, int ABL = 0, int PRIO = 0>
+template <int EPI, int NT, int ABL = 0, int PRIO = 0, int VEC = 2>
 __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kernel(GemmLaunch g)
 {
     constexpr int BN = 64 * NT;
-    constexpr int NB = 4 * NT;                 // float2 staging units per thread for the B tile
+    typedef float vNf __attribute__((ext_vector_type(VEC)));
+    typedef const vNf __attribute__((address_space(1)))* gcfN;
+    constexpr int UPR = BK / VEC;              // staging units (VEC floats) per row
+    constexpr int RPI = 256 / UPR;             // rows covered by one staging pass of the 256 threads
+    constexpr int NA = BM / RPI, NB = BN / RPI; // float2 staging units per thread for the A / B tile
     __shared__ __attribute__((aligned(16))) float sA[BM * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float sB[BN * LDS_STRIDE];
 
     // XCD-aware work mapping (speed only, never correctness).  Workgroups are dealt round-robin
-    // over the 8 XCDs, each with a private 4 MiB L2.  m-tiles are grouped in chunks of MCHUNK;
+    // over the 8 XCDs, each with a private 4 MiB L2.  m-tiles are grouped in chunks of g.mchunk (<= 8);
     // chunk c is pinned to the blocks with blockIdx % 8 == c % 8, and inside a chunk the column
     // tiles are the OUTER loop (heaviest K first, table order) and the m-tiles the inner one, so
     // the workgroups resident on one XCD share both their X row-tiles and their W column-tiles
@@ -59,12 +70,13 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
     // (measured: L2 hit rate 51 % -> 85 %, fetch 255 -> 59 MB per launch).
     const int m_tiles = (g.M + BM - 1) / BM;
     const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
-    const int per_chunk = MCHUNK * g.n_tiles;
+    const int mchunk = g.mchunk;
+    const int per_chunk = mchunk * g.n_tiles;
     const int chunk = (lidx / per_chunk) * 8 + xcd;
     const int rem = lidx % per_chunk;
-    const int m_tile = chunk * MCHUNK + rem % MCHUNK;
+    const int m_tile = chunk * mchunk + rem % mchunk;
     if (m_tile >= m_tiles) return;
-    const int2 tj = g.tiles[rem / MCHUNK];
+    const int2 tj = g.tiles[rem / mchunk];
     const GemmJob job = g.jobs[tj.x];
     const int n0 = tj.y * BN;
     const int m0 = m_tile * BM;
@@ -76,6 +88,8 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, r32 = lane & 31;
+    unsigned long long t_begin = 0, c_begin = 0;
+    if (ABL & 16) { t_begin = __builtin_amdgcn_s_memrealtime(); c_begin = __builtin_amdgcn_s_memtime(); }
 
     // columns of this lane (one per 32-wide sub-tile); biases are fetched before the main loop
     const int ncol0 = n0 + 32 * NT * wn + r32;
@@ -90,20 +104,20 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
     const bool wave_live = (n0 + 32 * NT * wn) < N;
 
     // staging map: float2 units, 16 per 32-float row; row offsets are loop invariant
-    const int s_row = tid >> 4;           // 0..15 (+16*i)
-    const int s_k = (tid & 15) * 2;
+    const int s_row = tid / UPR;          // + RPI*i
+    const int s_k = (tid % UPR) * VEC;
     // (32-bit element offsets from the wave-uniform bases: half the registers of 64-bit pointers,
     // and the loads take the scalar-base + vector-offset form; all buffers are far below 2^31 floats)
-    unsigned oa[8], ob[NB];
+    unsigned oa[NA], ob[NB];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int row = m0 + s_row + 16 * i;
+    for (int i = 0; i < NA; ++i) {
+        int row = m0 + s_row + RPI * i;
         row = row < M ? row : M - 1;
         oa[i] = (unsigned)row * (unsigned)g.ldx + s_k;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        int row = n0 + s_row + 16 * i;
+        int row = n0 + s_row + RPI * i;
         row = row < N ? row : N - 1;
         ob[i] = (unsigned)row * (unsigned)K + s_k;
     }
@@ -113,24 +127,24 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) acc[i][jn] = (v16f){0};
-    v2f ra[8], rb[NB];
+    vNf ra[NA], rb[NB];
     v4f fa_keep[2] = {}, fb_keep[NT] = {};   // used by the ABL & 8 measurement variant only
 
     // K is even, so a float2 is either fully inside or fully outside [0, K)
     auto gload = [&](int k0) {
         if (k0 + BK <= K) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ra[i] = *(gcf2)(X + (oa[i] + k0));
+            for (int i = 0; i < NA; ++i) ra[i] = *(gcfN)(X + (oa[i] + k0));
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = *(gcf2)(W + (ob[i] + k0));
+            for (int i = 0; i < NB; ++i) rb[i] = *(gcfN)(W + (ob[i] + k0));
         } else {
             const bool kin = k0 + s_k < K;
             const int kk = kin ? k0 : -s_k;     // any valid address; the value is zeroed below
             const float zm = kin ? 1.f : 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ra[i] = *(gcf2)(X + (oa[i] + kk)) * zm;
+            for (int i = 0; i < NA; ++i) ra[i] = *(gcfN)(X + (oa[i] + kk)) * zm;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = *(gcf2)(W + (ob[i] + kk)) * zm;
+            for (int i = 0; i < NB; ++i) rb[i] = *(gcfN)(W + (ob[i] + kk)) * zm;
         }
     };
 
@@ -144,21 +158,21 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
         if (!(ABL & 4) || k0 == 0) {
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<v2f*>(&sA[(s_row + 16 * i) * LDS_STRIDE + s_k]) = ra[i];
+            for (int i = 0; i < NA; ++i)
+                *reinterpret_cast<vNf*>(&sA[(s_row + RPI * i) * LDS_STRIDE + s_k]) = ra[i];
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                *reinterpret_cast<v2f*>(&sB[(s_row + 16 * i) * LDS_STRIDE + s_k]) = rb[i];
+                *reinterpret_cast<vNf*>(&sB[(s_row + RPI * i) * LDS_STRIDE + s_k]) = rb[i];
             __syncthreads();
         }
         if (k0 + BK < K && !(ABL & 1)) gload(k0 + BK);
         if (!wave_live) continue;
         if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 
-        const float* pa0 = &sA[(64 * wm + r32) * LDS_STRIDE + 16 * half];
-        const float* pb0 = &sB[(32 * NT * wn + r32) * LDS_STRIDE + 16 * half];
+        const float* pa0 = &sA[(64 * wm + r32) * LDS_STRIDE + (BK / 2) * half];
+        const float* pb0 = &sB[(32 * NT * wn + r32) * LDS_STRIDE + (BK / 2) * half];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < BK / 8; ++j) {
             v4f a[2], b[NT];
             if ((ABL & 8) && k0 > 0) {      // measurement only: no LDS reads after the first slab
 #pragma unroll
@@ -187,6 +201,13 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
         if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
 
+    if ((ABL & 16) && lane == 0 && g.tap) {     // measurement only: where and when did every wave of this workgroup run
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(g.tap) + 4 * ((size_t)blockIdx.x * 4 + wave);
+        d[0] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);      // HW_REG_XCC_ID
+        d[1] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4) | ((__builtin_amdgcn_s_memtime() - c_begin) << 20);   // HW_REG_HW_ID | shader cycles
+        d[2] = t_begin;
+        d[3] = __builtin_amdgcn_s_memrealtime();
+    }
     // epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
     if (!wave_live) return;
     const int mrow0 = m0 + 64 * wm + 4 * half;
@@ -229,18 +250,21 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
     }
 }
 
-template <int NT, int ABL, int PRIO = 0>
-static void launch_gemm_nt(const GemmLaunch& g, hipStream_t stream)
+
+template <int NT, int ABL, int PRIO = 0, int VEC = 2>
+static void launch_gemm_nt(const GemmLaunch& g_in, hipStream_t stream)
 {
+    GemmLaunch g = g_in;
     const int m_tiles = (g.M + BM - 1) / BM;
-    const int chunks = (m_tiles + MCHUNK - 1) / MCHUNK;
+    g.mchunk = gemm_mchunk(m_tiles);
+    const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
     const int chunks_per_xcd = (chunks + 7) / 8;
-    dim3 grid(8 * chunks_per_xcd * MCHUNK * g.n_tiles), block(256);
+    dim3 grid(8 * chunks_per_xcd * g.mchunk * g.n_tiles), block(256);
     switch (g.epilogue) {
-    case EPI_LINEAR: hipLaunchKernelGGL((gemm_f32_kernel<EPI_LINEAR, NT, ABL, PRIO>), grid, block, 0, stream, g); break;
-    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_f32_kernel<EPI_LEAKY, NT, ABL, PRIO>), grid, block, 0, stream, g); break;
-    case EPI_RES:    hipLaunchKernelGGL((gemm_f32_kernel<EPI_RES, NT, ABL, PRIO>), grid, block, 0, stream, g); break;
-    default:         hipLaunchKernelGGL((gemm_f32_kernel<EPI_MASK, NT, ABL, PRIO>), grid, block, 0, stream, g); break;
+    case EPI_LINEAR: hipLaunchKernelGGL((gemm_f32_kernel<EPI_LINEAR, NT, ABL, PRIO, VEC>), grid, block, 0, stream, g); break;
+    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_f32_kernel<EPI_LEAKY, NT, ABL, PRIO, VEC>), grid, block, 0, stream, g); break;
+    case EPI_RES:    hipLaunchKernelGGL((gemm_f32_kernel<EPI_RES, NT, ABL, PRIO, VEC>), grid, block, 0, stream, g); break;
+    default:         hipLaunchKernelGGL((gemm_f32_kernel<EPI_MASK, NT, ABL, PRIO, VEC>), grid, block, 0, stream, g); break;
     }
 }
 
@@ -248,10 +272,11 @@ void launch_gemm(const GemmLaunch& g, hipStream_t stream)
 {
     if (g.M <= 0 || g.n_tiles <= 0) return;
     // PRIO = 1 (s_setprio around the MFMA cluster) measured +3..5 % on the 64-wide kernel, 0 on the 128-wide
+    // every job is 16-byte aligned (band-padded layouts, weight rows padded to multiples of 4): dwordx4 loads
     if (g.tile_n == 128)
-        launch_gemm_nt<2, 0, 0>(g, stream);
+        launch_gemm_nt<2, 0, 0, 4>(g, stream);
     else
-        launch_gemm_nt<1, 0, 1>(g, stream);
+        launch_gemm_nt<1, 0, 1, 4>(g, stream);
 }
 
 }  // namespace bsrnn

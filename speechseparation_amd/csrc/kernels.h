@@ -36,6 +36,7 @@ struct GemmLaunch {
     const int2* tiles;       // device array [n_tiles]: (job index, column-tile index inside the job)
     int n_tiles;
     int tile_n;              // column-tile width of this launch: 64 or 128
+    int mchunk;              // m-tiles per XCD-pinned chunk (filled in by launch_gemm)
     const float* X; int ldx;
     float* Y; int ldy;
     const float* R; int ldr;
@@ -45,6 +46,7 @@ struct GemmLaunch {
     int epilogue;
 };
 void launch_gemm(const GemmLaunch& g, hipStream_t stream);
+constexpr int GEMM_BM = 128;
 
 // ------------------------------------------------------------------ dual-path LSTM kernels
 // Band-axis BLSTM layer (both directions in one launch): N sequences of length L.
@@ -66,17 +68,21 @@ struct FftTables {           // device tables, built once per context (double pr
     const float* hann;       // periodic Hann(2048)
     const float* inv_env;    // 1 / (w^2[i] + w^2[i+1024]), i < 1024   (torch.istft envelope)
     const float* inv_wsum;   // 1 / (w[i] + w[i+1024]),   i < 1024   (infer-streaming.py:145)
+    // band-padded spectrum layout: bin k's (re, im) sit at columns colmap[k], colmap[k]+1 of a row of ld floats;
+    // every band starts at a multiple of 4 floats so that the first Linear layer can use 16-byte loads
+    const int* colmap;       // [1025]
+    int ld;
 };
-// wave [R][n] -> X frame-major [R*T][2050] (re/im interleaved), reflect padding, Hann.
+// wave [R][n] -> X frame-major [R*T][ld] (re/im interleaved, band-padded columns), reflect padding, Hann.
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s);
-// Y frame-major [R*T][2050] -> windowed synthesis frames [R*T][2048] -> wave_out [R][(T-1)*1024]
+// Y frame-major [R*T][ld] -> windowed synthesis frames [R*T][2048] -> wave_out [R][(T-1)*1024]
 void launch_istft_frames(const FftTables& tb, const float* Y, float* frames, int M, hipStream_t s);
 void launch_istft_ola(const FftTables& tb, const float* frames, float* out, int R, int T, hipStream_t s);
-// [C][2050][T] <-> [C*T][2050]
-void launch_to_frame_major(const float* x, float* xf, int C, int T, hipStream_t s);
-void launch_from_frame_major(const float* yf, float* y, int C, int T, hipStream_t s);
+// [C][2050][T] (reference layout) <-> [C*T][ld] (band-padded)
+void launch_to_frame_major(const FftTables& tb, const float* x, float* xf, int C, int T, hipStream_t s);
+void launch_from_frame_major(const FftTables& tb, const float* yf, float* y, int C, int T, hipStream_t s);
 // streaming DSP, one frame per row (infer-streaming.py:116-145)
-//   analysis: buf [C][2048] slides by 1024, appends chunk [C][1024]; X [C][2050] = rfft(buf*hann)
+//   analysis: buf [C][2048] slides by 1024, appends chunk [C][1024]; X [C][ld] = rfft(buf*hann)
 //   synthesis: s = irfft(mix(Y, X)); out = (s[0:1024] + prev[1024:2048]) * inv_wsum; prev = s
 void launch_stream_analysis(const FftTables& tb, float* buf, const float* chunk, float* X, int C, hipStream_t s);
 void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, float mix,

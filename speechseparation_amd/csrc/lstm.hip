@@ -35,8 +35,11 @@ __device__ __forceinline__ float fast_tanh(float x)
 // c lives in registers; h_t goes to LDS (next step's A operand) and from there, coalesced,
 // to global.  x_{t+1} is prefetched into registers during the MFMAs of step t.
 // =====================================================================================
+#ifndef BAND_OCC
+#define BAND_OCC 2            // waves per SIMD requested for the band kernel (2 workgroups per CU)
+#endif
 template <int IN>
-__global__ __launch_bounds__(256) void band_lstm_kernel(const float* __restrict__ xin, float* __restrict__ hout,
+__global__ __launch_bounds__(256, BAND_OCC) void band_lstm_kernel(const float* __restrict__ xin, float* __restrict__ hout,
                                                         const float* __restrict__ wpk, const float* __restrict__ bias,
                                                         int N, int L)
 {
