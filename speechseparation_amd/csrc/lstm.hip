@@ -166,24 +166,22 @@ void launch_band_lstm(const float* xin, float* hout, const float* wpk, const flo
 // The recurrence is latency bound (T sequential steps), so a workgroup takes only FOUR
 // sequences and the gates are computed with v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4x4,
 // A = 4 sequences (the same for every block), B = 4 gate columns per block, i.e. 64 gate
-// columns per wave = 16 hidden units x {i,f,g,o}.  Lane 4b+j holds gate j of unit 16w+b for
-// the four sequences in its four accumulator registers; the i/f/g/o of a unit are gathered
-// inside the quad with DPP quad_perm broadcasts.  [W_ih | W_hh] (128 k) of the wave's 64
-// columns is register resident; c is register resident (replicated over the quad).
+// columns per wave = 16 hidden units x {i,f,g,o}.  The WEIGHTS are the MFMA's A operand (lane 4b+i
+// holds the row of gate i of unit 16w+b) and the activations its B operand (lane 4b+j supplies
+// sequence j), so D[i][j] puts the four gates i,f,g,o of ONE (unit, sequence) into the four
+// accumulator registers of ONE lane: the cell update needs no cross-lane traffic and each of
+// the 64 lanes updates exactly one cell (a first version with the operands the other way round
+// needed 16 DPP broadcasts and 4x redundant cell math: 44 % of every step went into VALU issue,
+// which starves next to a stream of 8-cycle MFMAs).  [W_ih | W_hh] (128 k) of the wave's 64 rows
+// and the cell state c are register resident.
 // =====================================================================================
 constexpr int TCH = 8;        // x steps staged per chunk
 constexpr int TS = HID + 4;   // LDS row stride (68 floats: 4 rows hit 4 distinct b128 slots)
 
-template <int CTRL>
-__device__ __forceinline__ float quad_bcast(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-
 __global__ __launch_bounds__(512) void time_lstm_kernel(const float* __restrict__ zin, float* __restrict__ hout,
                                                         const float* __restrict__ wpk, const float* __restrict__ bias,
                                                         const float* __restrict__ state_in, float* __restrict__ state_out,
-                                                        int R, int T, int K)
+                                                        int R, int T, int K, unsigned long long* __restrict__ dbg)
 {
     __shared__ __attribute__((aligned(16))) float xbuf[2][TCH][4 * TS];
     __shared__ __attribute__((aligned(16))) float h0buf[2][4 * TS];
@@ -208,15 +206,13 @@ __global__ __launch_bounds__(512) void time_lstm_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 2 * HID; ++k) w[k] = wp[(size_t)k * 64];
     }
-    const float bs = bias[layer * 256 + j * 64 + unit];
-
-    // c of (sequence i, this unit), replicated over the quad; h_{-1} into LDS slot 1
-    float c[4];
+    // this lane's weight row is gate j of `unit` (A operand); its cell is (unit, sequence j)
+    v4f bs4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ni = n0 + i; ni = ni < N ? ni : N - 1;
-        c[i] = state_in ? state_in[((size_t)(2 + layer) * N + ni) * HID + unit] : 0.f;
-    }
+    for (int gte = 0; gte < 4; ++gte) bs4[gte] = bias[layer * 256 + gte * 64 + unit];
+
+    // c of (sequence j, this unit); h_{-1} into LDS slot 1
+    float c = state_in ? state_in[((size_t)(2 + layer) * N + nj) * HID + unit] : 0.f;
     {
         const float hinit = state_in ? state_in[((size_t)layer * N + nj) * HID + unit] : 0.f;
         float* hb = layer ? h1buf[1] : h0buf[1];
@@ -243,13 +239,14 @@ __global__ __launch_bounds__(512) void time_lstm_kernel(const float* __restrict_
     float hsel = 0.f, csel = 0.f;
     __syncthreads();
 
-    // Gate accumulators (4 independent MFMA chains).  The two layer-groups run the same work in a
-    // different order so that one group's cell update (VALU/transcendental) overlaps the other
-    // group's MFMAs on the shared SIMD:
-    //   layer 0, iteration s:  W_h.h0_{s-1} -> cell(s) -> publish h0_s -> bias + W_x.x_{s+1} (for s+1)
-    //   layer 1, iteration s:  bias + W_x.h0_{s-1} -> W_h.h1_{s-2} -> cell(s-1) -> publish h1_{s-1}
+    // Gate accumulators (4 independent MFMA chains).  Both layer-groups run the same phase order in
+    // lockstep: 128 MFMAs (input half + recurrent half), then the cell.  VALU issue starves next to a
+    // stream of 8-cycle MFMAs from the SIMD's other wave (measured: ~20 cycles per VALU instruction), so
+    // the two waves of a SIMD should be in their (short) VALU phases at the same time:
+    //   layer 0, iteration s:  bias + W_x.x_s      + W_h.h0_{s-1} -> cell(s)   -> publish h0_s
+    //   layer 1, iteration s:  bias + W_x.h0_{s-1} + W_h.h1_{s-2} -> cell(s-1) -> publish h1_{s-1}
     // h_t of either layer lives in LDS slot t & 1; one workgroup barrier per iteration.
-    v4f a0 = {bs, bs, bs, bs}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+    v4f a0 = bs4, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
     auto gemv64 = [&](const float* src, const int wofs) {
         // all 16 reads first: a 4x4x1 MFMA lasts 8 cycles, so reads trickled in between groups of
         // four MFMAs leave the chain waiting on LDS latency (measured: MFMA pipe 33 % busy)
@@ -259,63 +256,55 @@ __global__ __launch_bounds__(512) void time_lstm_kernel(const float* __restrict_
         __builtin_amdgcn_sched_barrier(0);        // keep hipcc from sinking the reads back between the MFMAs
 #pragma unroll
         for (int m = 0; m < HID / 4; ++m) {
-            a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m][0], w[wofs + 4 * m + 0], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m][1], w[wofs + 4 * m + 1], a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m][2], w[wofs + 4 * m + 2], a2, 0, 0, 0);
-            a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[m][3], w[wofs + 4 * m + 3], a3, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[wofs + 4 * m + 0], av[m][0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[wofs + 4 * m + 1], av[m][1], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[wofs + 4 * m + 2], av[m][2], a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[wofs + 4 * m + 3], av[m][3], a3, 0, 0, 0);
         }
     };
     auto reset_acc = [&]() {
-        a0 = (v4f){bs, bs, bs, bs};
+        a0 = bs4;
         a1 = a2 = a3 = (v4f){0.f, 0.f, 0.f, 0.f};
     };
     auto cell = [&](int t) {
-        const v4f gsum = (a0 + a1) + (a2 + a3);
-        // this lane's gate type j: tanh for g (j == 2), sigmoid otherwise; tanh(x) = 2 sigmoid(2x) - 1
-        const float sc = (j == 2) ? 2.f : 1.f;
-        float hnew[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float sg = fast_sigmoid(sc * gsum[i]);
-            const float act = sc * sg - (sc - 1.f);
-            const float ig = quad_bcast<0x00>(act);
-            const float fg = quad_bcast<0x55>(act);
-            const float gg = quad_bcast<0xAA>(act);
-            const float og = quad_bcast<0xFF>(act);
-            c[i] = fg * c[i] + ig * gg;
-            hnew[i] = og * fast_tanh(c[i]);
-        }
-        hsel = j == 0 ? hnew[0] : j == 1 ? hnew[1] : j == 2 ? hnew[2] : hnew[3];
-        csel = j == 0 ? c[0] : j == 1 ? c[1] : j == 2 ? c[2] : c[3];
+        const v4f gsum = (a0 + a1) + (a2 + a3);          // i, f, g, o pre-activations of (unit, sequence j)
+        const float ig = fast_sigmoid(gsum[0]);
+        const float fg = fast_sigmoid(gsum[1]);
+        const float gg = fast_tanh(gsum[2]);
+        const float og = fast_sigmoid(gsum[3]);
+        c = fg * c + ig * gg;
+        hsel = og * fast_tanh(c);
+        csel = c;
         float* hb = layer ? h1buf[t & 1] : h0buf[t & 1];
         hb[j * TS + unit] = hsel;
         if (layer && nj_raw < N) hout[base_j + (size_t)t * tstride + unit] = hsel;
     };
-    if (layer == 0) gemv64(&xbuf[0][0][j * TS], 0);          // input half of step 0
-
+    // measurement only (dbg != nullptr): 100 MHz stamps per phase, accumulated per wave
+    unsigned long long tp[4] = {0, 0, 0, 0}, tq = 0;
+    auto stamp = [&](int k) { if (dbg) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); tp[k] += n - tq; tq = n; } };
+    if (dbg) tq = __builtin_amdgcn_s_memrealtime();
     for (int s = 0; s <= T; ++s) {
         const int chunk = s / TCH, sin = s % TCH;
         const bool have_next = (chunk + 1) * TCH < T;
         if (sin == 0 && have_next) xnext = chunk_load(chunk + 1);
 
-        if (layer == 0) {
-            if (s < T) {
-                gemv64(&h0buf[(s + 1) & 1][j * TS], HID);                 // recurrent half, h0_{s-1}
-                cell(s);
-                if (s + 1 < T) {                                          // input half of step s+1
-                    reset_acc();
-                    gemv64(&xbuf[((s + 1) / TCH) & 1][(s + 1) % TCH][j * TS], 0);
-                }
-            }
-        } else if (s >= 1) {
-            const int t = s - 1;
+        stamp(3);                                                         // barrier + loop overhead
+        const int t = layer ? s - 1 : s;                                  // the time step this wave computes
+        if (layer ? (s >= 1) : (s < T)) {
             reset_acc();
-            gemv64(&h0buf[t & 1][j * TS], 0);                             // input half: h0_t
-            gemv64(&h1buf[(t + 1) & 1][j * TS], HID);                     // recurrent half: h1_{t-1}
+            gemv64(layer ? &h0buf[t & 1][j * TS] : &xbuf[chunk & 1][sin][j * TS], 0);          // input half
+            stamp(2);
+            gemv64(layer ? &h1buf[(t + 1) & 1][j * TS] : &h0buf[(t + 1) & 1][j * TS], HID);    // recurrent half, h_{t-1}
+            stamp(0);
             cell(t);
+            stamp(1);
         }
-        if (sin == TCH - 2 && have_next) chunk_store(chunk + 1, xnext);
+        if (sin == TCH - 1 && have_next) chunk_store(chunk + 1, xnext);
         __syncthreads();
+    }
+    if (dbg && lane == 0 && blockIdx.x < 4) {
+        unsigned long long* d = dbg + (blockIdx.x * 8 + wave) * 4;
+        d[0] = tp[0]; d[1] = tp[1]; d[2] = tp[2]; d[3] = tp[3];
     }
 
     if (state_out && nj_raw < N) {
@@ -330,7 +319,8 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const flo
     const int N = R * K;
     if (N <= 0 || T <= 0) return;
     dim3 grid((N + 3) / 4), block(512);
-    hipLaunchKernelGGL(time_lstm_kernel, grid, block, 0, stream, zin, hout, wpk, bias, state_in, state_out, R, T, K);
+    hipLaunchKernelGGL(time_lstm_kernel, grid, block, 0, stream, zin, hout, wpk, bias, state_in, state_out, R, T, K,
+                       (unsigned long long*)nullptr);
 }
 
 }  // namespace bsrnn
