@@ -105,6 +105,14 @@ struct bsrnn_stream {
     bsrnn_ctx* ctx;
     int C;
     float *buf, *prev, *state, *X, *Y, *chunk, *out;
+    float* mixp;                       // device word holding the wet/dry control (read by the synthesis kernel)
+    float *h_in = nullptr, *h_out = nullptr;   // pinned staging for the host-buffer entry point
+    // One step = ~27 tiny launches; its buffers are fixed, so the whole step is captured once into a
+    // hipGraph and replayed (launch-bound inner loop: 477 us eager per step at C = 2).
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    hipStream_t cap = nullptr;
+    bool use_graph = true;
 };
 
 namespace {
@@ -901,7 +909,7 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     bsrnn_stream* st = new bsrnn_stream();
     st->ctx = c; st->C = C;
     const size_t nstate = (size_t)4 * 2 * C * c->K * HID;
-    const size_t total = (size_t)C * (NFFT * 2 + (size_t)c->LDP * 2 + HOPS * 2) + nstate;
+    const size_t total = (size_t)C * (NFFT * 2 + (size_t)c->LDP * 2 + HOPS * 2) + nstate + 4;
     float* p = nullptr;
     hipError_t e = hipMalloc((void**)&p, total * sizeof(float));
     if (e != hipSuccess) { delete st; return fail(BSRNN_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -911,7 +919,13 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     st->Y = p; p += (size_t)C * c->LDP;
     st->chunk = p; p += (size_t)C * HOPS;
     st->out = p; p += (size_t)C * HOPS;
-    st->state = p;
+    st->state = p; p += nstate;
+    st->mixp = p;
+    st->use_graph = getenv("BSRNN_NO_GRAPH") == nullptr;
+    if (hipHostMalloc((void**)&st->h_in, (size_t)C * HOPS * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&st->h_out, (size_t)C * HOPS * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(st->buf); delete st; return fail(BSRNN_EHIP, "hipHostMalloc failed");
+    }
     e = hipMemset(st->buf, 0, total * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(st->buf); delete st; return fail(BSRNN_EHIP, "hipMemset: %s", hipGetErrorString(e)); }
     rc = ensure_ws(c, C);
@@ -925,6 +939,11 @@ void bsrnn_stream_destroy(bsrnn_stream* st)
     if (!st) return;
     (void)hipSetDevice(st->ctx->device);
     (void)hipDeviceSynchronize();
+    if (st->exec) (void)hipGraphExecDestroy(st->exec);
+    if (st->graph) (void)hipGraphDestroy(st->graph);
+    if (st->cap) (void)hipStreamDestroy(st->cap);
+    if (st->h_in) (void)hipHostFree(st->h_in);
+    if (st->h_out) (void)hipHostFree(st->h_out);
     (void)hipFree(st->buf);
     delete st;
 }
@@ -934,8 +953,19 @@ int bsrnn_stream_reset(bsrnn_stream* st, void* stream)
     if (!st) return fail(BSRNN_EARG, "null stream");
     HIP_TRY(hipSetDevice(st->ctx->device));
     const size_t nstate = (size_t)4 * 2 * st->C * st->ctx->K * HID;
-    const size_t total = (size_t)st->C * (NFFT * 2 + (size_t)st->ctx->LDP * 2 + HOPS * 2) + nstate;
+    const size_t total = (size_t)st->C * (NFFT * 2 + (size_t)st->ctx->LDP * 2 + HOPS * 2) + nstate + 4;
     HIP_TRY(hipMemsetAsync(st->buf, 0, total * sizeof(float), (hipStream_t)stream));
+    return 0;
+}
+
+// the launches of one streaming step on the stream object's own buffers (st->chunk -> st->out)
+static int stream_step_launches(bsrnn_stream* st, hipStream_t s)
+{
+    bsrnn_ctx* c = st->ctx;
+    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_analysis(c->tb, st->buf, st->chunk, st->X, st->C, s); }
+    int rc = run_model(c, st->X, st->Y, nullptr, st->C, 1, st->state, st->state, s);
+    if (rc) return rc;
+    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_synthesis(c->tb, st->Y, st->X, st->mixp, st->prev, st->out, st->C, s); }
     return 0;
 }
 
@@ -946,9 +976,26 @@ int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mi
     int rc = check_ready(c);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_analysis(c->tb, st->buf, chunk, st->X, st->C, s); }
-    if ((rc = run_model(c, st->X, st->Y, nullptr, st->C, 1, st->state, st->state, s))) return rc;
-    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_synthesis(c->tb, st->Y, st->X, mix, st->prev, out, st->C, s); }
+    const size_t nb = (size_t)st->C * HOPS * sizeof(float);
+    if (chunk != st->chunk) HIP_TRY(hipMemcpyAsync(st->chunk, chunk, nb, hipMemcpyDeviceToDevice, s));
+    int mix_bits;
+    memcpy(&mix_bits, &mix, sizeof mix_bits);
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)st->mixp, mix_bits, 1, s));
+    if (st->use_graph && c->prof == 0) {
+        if (!st->exec) {      // capture once: every pointer inside the step belongs to the stream object / context
+            if (!st->cap) HIP_TRY(hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking));
+            HIP_TRY(hipStreamBeginCapture(st->cap, hipStreamCaptureModeThreadLocal));
+            rc = stream_step_launches(st, st->cap);
+            hipError_t e = hipStreamEndCapture(st->cap, &st->graph);
+            if (rc) return rc;
+            if (e != hipSuccess) return fail(BSRNN_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIP_TRY(hipGraphInstantiate(&st->exec, st->graph, nullptr, nullptr, 0));
+        }
+        HIP_TRY(hipGraphLaunch(st->exec, s));
+    } else if ((rc = stream_step_launches(st, s))) {
+        return rc;
+    }
+    if (out != st->out) HIP_TRY(hipMemcpyAsync(out, st->out, nb, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -958,11 +1005,13 @@ int bsrnn_stream_step_host(bsrnn_stream* st, const float* chunk_host, float* out
     if (!st || !chunk_host || !out_host) return fail(BSRNN_EARG, "bsrnn_stream_step_host: null argument");
     HIP_TRY(hipSetDevice(st->ctx->device));
     const size_t nb = (size_t)st->C * HOPS * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(st->chunk, chunk_host, nb, hipMemcpyHostToDevice, nullptr));
+    memcpy(st->h_in, chunk_host, nb);
+    HIP_TRY(hipMemcpyAsync(st->chunk, st->h_in, nb, hipMemcpyHostToDevice, nullptr));
     int rc = bsrnn_stream_step(st, st->chunk, st->out, mix, nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out_host, st->out, nb, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(st->h_out, st->out, nb, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
+    memcpy(out_host, st->h_out, nb);
     return 0;
 }
 

@@ -17,21 +17,42 @@ __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y
 
 // In-LDS complex FFT of 1024 points, Stockham autosort radix-4.  z0 holds the input, the
 // result ends in the returned buffer.  INV = true computes the unnormalised inverse.
+// Twiddles of the four non-trivial passes, fetched once per thread BEFORE the passes start (they
+// depend only on the thread index): a global load inside each pass would put an L2 round trip into
+// the dependent chain of every pass.
+struct Twiddles { float2 t[4][3]; };
 template <bool INV>
-__device__ __forceinline__ float2* fft1024(float2* z0, float2* z1, const float2* __restrict__ tw, int tid)
+__device__ __forceinline__ Twiddles load_twiddles(const float2* __restrict__ tw, int tid)
+{
+    Twiddles r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int p = 4 << (2 * q);                 // 4, 16, 64, 256
+        const int k = tid & (p - 1);
+        const int step = 256 / p;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            float2 t = tw[(m + 1) * k * step];
+            if (INV) t = cconj(t);
+            r.t[q][m] = t;
+        }
+    }
+    return r;
+}
+
+template <bool INV>
+__device__ __forceinline__ float2* fft1024(float2* z0, float2* z1, const Twiddles& twd, int tid)
 {
     float2* src = z0;
     float2* dst = z1;
 #pragma unroll
-    for (int p = 1; p < 1024; p <<= 2) {
+    for (int q = 0; q < 5; ++q) {
+        const int p = 1 << (2 * q);
         const int k = tid & (p - 1);
         const int jo = ((tid - k) << 2) + k;
-        const int step = 256 / p;                 // W_{4p}^k = W_1024^{k*256/p}
         float2 u0 = src[tid], u1 = src[tid + 256], u2 = src[tid + 512], u3 = src[tid + 768];
-        if (p > 1) {
-            float2 t1 = tw[k * step], t2 = tw[2 * k * step], t3 = tw[3 * k * step];
-            if (INV) { t1 = cconj(t1); t2 = cconj(t2); t3 = cconj(t3); }
-            u1 = cmul(u1, t1); u2 = cmul(u2, t2); u3 = cmul(u3, t3);
+        if (q > 0) {
+            u1 = cmul(u1, twd.t[q - 1][0]); u2 = cmul(u2, twd.t[q - 1][1]); u3 = cmul(u3, twd.t[q - 1][2]);
         }
         const float2 v0 = cadd(u0, u2), v1 = csub(u0, u2), v2 = cadd(u1, u3), d = csub(u1, u3);
         const float2 v3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);   // (+i or -i) * d
@@ -84,6 +105,7 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
+    const Twiddles twd = load_twiddles<false>(tb.tw1024, tid);
     const int m = blockIdx.x;                  // r*T + t
     const int r = m / T, t = m % T;
     const float* src = wave + (size_t)r * n;
@@ -101,7 +123,7 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
         z0[c] = make_float2(v[0], v[1]);
     }
     __syncthreads();
-    const float2* Z = fft1024<false>(z0, z1, tb.tw1024, tid);
+    const float2* Z = fft1024<false>(z0, z1, twd, tid);
     rfft_split_store(Z, tb.tw2048, X + (size_t)m * tb.ld, tb.colmap, tid);
 }
 
@@ -115,10 +137,11 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(FftTables tb, const f
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
+    const Twiddles twd = load_twiddles<true>(tb.tw1024, tid);
     const size_t m = blockIdx.x;
     irfft_merge(Y + m * tb.ld, tb.tw2048, z0, tb.colmap, tid);
     __syncthreads();
-    const float2* z = fft1024<true>(z0, z1, tb.tw1024, tid);
+    const float2* z = fft1024<true>(z0, z1, twd, tid);
     float* dst = frames + m * NFFT;
     const float sc = 1.0f / 1024.0f;
     for (int c = tid; c < 1024; c += 256) {
@@ -215,6 +238,7 @@ __global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, floa
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
+    const Twiddles twd = load_twiddles<false>(tb.tw1024, tid);
     const int c = blockIdx.x;
     float* b = buf + (size_t)c * NFFT;
     const float* ch = chunk + (size_t)c * HOPS;
@@ -236,16 +260,18 @@ __global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, floa
         z0[512 + cc] = make_float2(fresh[i].x * tb.hann[HOPS + 2 * cc], fresh[i].y * tb.hann[HOPS + 2 * cc + 1]);
     }
     __syncthreads();
-    const float2* Z = fft1024<false>(z0, z1, tb.tw1024, tid);
+    const float2* Z = fft1024<false>(z0, z1, twd, tid);
     rfft_split_store(Z, tb.tw2048, X + (size_t)c * tb.ld, tb.colmap, tid);
 }
 
 __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, const float* __restrict__ Y, const float* __restrict__ X,
-                                                               float mix, float* __restrict__ prev, float* __restrict__ out)
+                                                               const float* __restrict__ mix_dev, float* __restrict__ prev, float* __restrict__ out)
 {
+    const float mix = *mix_dev;      // device word: the step is replayed from a hipGraph, the control value changes per call
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     __shared__ __attribute__((aligned(16))) float spec[F2 + 2];
     const int tid = threadIdx.x;
+    const Twiddles twd = load_twiddles<true>(tb.tw1024, tid);
     const int c = blockIdx.x;
     const float* y = Y + (size_t)c * tb.ld;
     const float* x = X + (size_t)c * tb.ld;
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, con
     __syncthreads();
     irfft_merge(spec, tb.tw2048, z0, nullptr, tid);
     __syncthreads();
-    const float2* z = fft1024<true>(z0, z1, tb.tw1024, tid);
+    const float2* z = fft1024<true>(z0, z1, twd, tid);
     float* pv = prev + (size_t)c * NFFT;
     float* o = out + (size_t)c * HOPS;
     const float sc = 1.0f / 1024.0f;
@@ -280,9 +306,9 @@ void launch_stream_analysis(const FftTables& tb, float* buf, const float* chunk,
 {
     hipLaunchKernelGGL(stream_analysis_kernel, dim3(C), dim3(256), 0, s, tb, buf, chunk, X);
 }
-void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, float mix, float* prev, float* out, int C, hipStream_t s)
+void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, const float* mix_dev, float* prev, float* out, int C, hipStream_t s)
 {
-    hipLaunchKernelGGL(stream_synthesis_kernel, dim3(C), dim3(256), 0, s, tb, Y, X, mix, prev, out);
+    hipLaunchKernelGGL(stream_synthesis_kernel, dim3(C), dim3(256), 0, s, tb, Y, X, mix_dev, prev, out);
 }
 
 }  // namespace bsrnn

@@ -85,7 +85,7 @@ void launch_from_frame_major(const FftTables& tb, const float* yf, float* y, int
 //   analysis: buf [C][2048] slides by 1024, appends chunk [C][1024]; X [C][ld] = rfft(buf*hann)
 //   synthesis: s = irfft(mix(Y, X)); out = (s[0:1024] + prev[1024:2048]) * inv_wsum; prev = s
 void launch_stream_analysis(const FftTables& tb, float* buf, const float* chunk, float* X, int C, hipStream_t s);
-void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, float mix,
+void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, const float* mix_dev,
                              float* prev, float* out, int C, hipStream_t s);
 
 }  // namespace bsrnn
