@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
     constexpr int UPR = BK / VEC;              // staging units (VEC floats) per row
     constexpr int RPI = 256 / UPR;             // rows covered by one staging pass of the 256 threads
     constexpr int NA = BM / RPI, NB = BN / RPI; // float2 staging units per thread for the A / B tile
-    __shared__ __attribute__((aligned(16))) float sA[BM * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float sB[BN * LDS_STRIDE];
+    // one LDS array: A tile, B tile; after the K loop the same memory stages the accumulators for the epilogue
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_STRIDE];
+    float* const sA = smem;
+    float* const sB = smem + BM * LDS_STRIDE;
 
     // XCD-aware work mapping (speed only, never correctness).  Workgroups are dealt round-robin
     // over the 8 XCDs, each with a private 4 MiB L2.  m-tiles are grouped in chunks of g.mchunk (<= 8);
@@ -208,48 +210,51 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
         d[2] = t_begin;
         d[3] = __builtin_amdgcn_s_memrealtime();
     }
-    // epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    if (!wave_live) return;
-    const int mrow0 = m0 + 64 * wm + 4 * half;
-    const bool full_rows = (m0 + BM <= M);
+    // Epilogue through LDS.  The C/D layout of the 32x32 MFMA (col = lane & 31, row = (reg & 3) + 8*(reg >> 2)
+    // + 4*(lane >> 5)) gives every lane a column, i.e. 4-byte accesses at a row stride; the residual /
+    // multiplier loads and the stores are therefore done from a row-major LDS image of the tile with 16 bytes
+    // per lane and whole 256-byte row segments per wave (the EPI_MASK launch spent 70 us = 43 % extra in its
+    // 4-byte epilogue).  Bias and LeakyReLU are applied on the way into LDS.  Two passes of 64 rows.
+    constexpr int ES = BN + 4;                          // row stride of the staged tile (floats)
+    static_assert(64 * ES <= (BM + BN) * LDS_STRIDE, "staging tile must fit the operand tiles");
+    float* const sE = smem;
+    const int my_col = 32 * NT * wn + r32;
 #pragma unroll
-    for (int jn = 0; jn < NT; ++jn) {
-        const int n = ncol0 + 32 * jn;
-        if (n >= N) continue;
-        const gf Y = (gf)(g.Y + job.y_off + n);
-        const gcf Rp = (EPI == EPI_RES || EPI == EPI_MASK) ? (gcf)(g.R + job.r_off + n) : nullptr;
-        const gcf Mp = (EPI == EPI_MASK) ? (gcf)(g.Mul + job.m_off + n) : nullptr;
-        const gf Tp = (EPI == EPI_MASK && g.tap) ? (gf)(g.tap + job.m_off + n) : nullptr;
-        const float bj = bias[jn];
-        auto finish = [&](float v, int m) {
-            v += bj;
-            if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
-            if (EPI == EPI_RES) v += Rp[(size_t)m * g.ldr];
-            if (EPI == EPI_MASK) {
-                v += Rp[(size_t)m * g.ldr];
-                if (Tp) Tp[(size_t)m * g.ldt] = v;
-                v *= Mp[(size_t)m * g.ldm];
-            }
-            Y[(size_t)m * g.ldy] = v;
-        };
-        if (full_rows) {               // full tile: straight-line stores, no per-row predicate
+    for (int hh = 0; hh < 2; ++hh) {
+        __syncthreads();                                // operand tiles (pass 0) / previous pass fully consumed
+        if (wm == hh && wave_live) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    finish(acc[i][jn][reg], mrow0 + 32 * i + (reg & 3) + 8 * (reg >> 2));
-        } else {
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float v = acc[i][jn][reg] + bias[jn];
+                        if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
+                        sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + my_col + 32 * jn] = v;
+                    }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 4;                     // float4 chunks per row
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int m = mrow0 + 32 * i + (reg & 3) + 8 * (reg >> 2);
-                    if (m < M) finish(acc[i][jn][reg], m);
+        for (int u = 0; u < 64 * CPR / 256; ++u) {
+            const int idx = tid + 256 * u;
+            const int row = idx / CPR, c4 = idx % CPR;
+            const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
+            // a chunk that straddles N stays inside the band's 4-aligned segment: its pad columns only need to be finite
+            if (m < M && n < N) {
+                v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
+                if (EPI == EPI_RES || EPI == EPI_MASK)
+                    v += *reinterpret_cast<const v4f __attribute__((address_space(1)))*>((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
+                if (EPI == EPI_MASK) {
+                    if (g.tap) *reinterpret_cast<v4f __attribute__((address_space(1)))*>((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
+                    v *= *reinterpret_cast<const v4f __attribute__((address_space(1)))*>((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
                 }
+                *reinterpret_cast<v4f __attribute__((address_space(1)))*>((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
+            }
         }
     }
 }
-
 
 template <int NT, int ABL, int PRIO = 0, int VEC = 2>
 static void launch_gemm_nt(const GemmLaunch& g_in, hipStream_t stream)
