@@ -66,35 +66,67 @@ __device__ __forceinline__ float2* fft1024(float2* z0, float2* z1, const Twiddle
     return src;
 }
 
-// real spectrum X[0..1024] from Z = FFT1024(x[2n] + i x[2n+1]); writes interleaved re/im
-__device__ __forceinline__ void rfft_split_store(const float2* Z, const float2* __restrict__ tw2048,
-                                                 float* __restrict__ out, const int* __restrict__ colmap, int tid)
+// Per-thread slice of the real-FFT split/merge step: bins k = tid + 256 i.  The column map and the
+// 2048-point twiddles are fetched up front (before the FFT passes) so that the bin loops below contain no
+// dependent global load -> global access chains.
+struct SplitCtx {
+    int col[5];          // column of bin tid + 256 i   (i = 4 only for tid == 0: bin 1024)
+    int colr[4];         // column of bin 1024 - (tid + 256 i)
+    float2 tw[5];
+};
+__device__ __forceinline__ SplitCtx load_split(const FftTables& tb, int tid, bool want_reverse)
 {
-    for (int k = tid; k <= 1024; k += 256) {
+    SplitCtx c;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int k = tid + 256 * i;
+        const bool ok = k <= 1024;
+        c.col[i] = ok && tb.colmap ? tb.colmap[k] : 2 * k;
+        c.tw[i] = ok ? tb.tw2048[k] : make_float2(0.f, 0.f);
+        if (i < 4) c.colr[i] = want_reverse ? (tb.colmap ? tb.colmap[1024 - k] : 2 * (1024 - k)) : 0;
+    }
+    return c;
+}
+
+// real spectrum X[0..1024] from Z = FFT1024(x[2n] + i x[2n+1]); writes interleaved re/im
+__device__ __forceinline__ void rfft_split_store(const float2* Z, const SplitCtx& sc, float* __restrict__ out, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int k = tid + 256 * i;
+        if (k > 1024) break;
         const float2 zk = Z[k & 1023];
         const float2 zc = cconj(Z[(1024 - k) & 1023]);
         const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
         const float2 dd = csub(zk, zc);                               // (zk - zc) / (2i)
         const float2 o = make_float2(0.5f * dd.y, -0.5f * dd.x);
-        float2 x = cadd(e, cmul(tw2048[k], o));
+        float2 x = cadd(e, cmul(sc.tw[i], o));
         if (k == 0 || k == 1024) x.y = 0.f;                           // exactly real for real input
-        *reinterpret_cast<float2*>(out + colmap[k]) = x;
+        *reinterpret_cast<float2*>(out + sc.col[i]) = x;
     }
 }
 
-// Z[k] = E[k] + i O[k] for the inverse; imaginary parts of DC / Nyquist are ignored like c2r does
-// colmap == nullptr: Y is a plain interleaved [2050] row
-__device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const float2* __restrict__ tw2048,
-                                            float2* z, const int* __restrict__ colmap, int tid)
+// Z[k] = E[k] + i O[k] for the inverse; imaginary parts of DC / Nyquist are ignored like c2r does.
+// `lin` = true: Y is a plain interleaved [2050] row (LDS copy), else columns come from sc.
+template <bool LIN>
+__device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const SplitCtx& sc, float2* z, int tid)
 {
-    for (int k = tid; k < 1024; k += 256) {
-        float2 xk = *reinterpret_cast<const float2*>(Y + (colmap ? colmap[k] : 2 * k));
-        float2 xc = *reinterpret_cast<const float2*>(Y + (colmap ? colmap[1024 - k] : 2 * (1024 - k)));
-        if (k == 0) { xk.y = 0.f; xc.y = 0.f; }
-        xc = cconj(xc);
-        const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y));
-        const float2 dd = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y));
-        const float2 o = cmul(dd, cconj(tw2048[k]));
+    float2 xk[4], xc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                     // all loads first
+        const int k = tid + 256 * i;
+        xk[i] = *reinterpret_cast<const float2*>(Y + (LIN ? 2 * k : sc.col[i]));
+        xc[i] = *reinterpret_cast<const float2*>(Y + (LIN ? 2 * (1024 - k) : sc.colr[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        float2 a = xk[i], b = xc[i];
+        if (k == 0) { a.y = 0.f; b.y = 0.f; }
+        b = cconj(b);
+        const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+        const float2 dd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+        const float2 o = cmul(dd, cconj(sc.tw[i]));
         z[k] = make_float2(e.x - o.y, e.y + o.x);                     // e + i*o
     }
 }
@@ -106,6 +138,7 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<false>(tb.tw1024, tid);
+    const SplitCtx spl = load_split(tb, tid, false);
     const int m = blockIdx.x;                  // r*T + t
     const int r = m / T, t = m % T;
     const float* src = wave + (size_t)r * n;
@@ -124,7 +157,7 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
     }
     __syncthreads();
     const float2* Z = fft1024<false>(z0, z1, twd, tid);
-    rfft_split_store(Z, tb.tw2048, X + (size_t)m * tb.ld, tb.colmap, tid);
+    rfft_split_store(Z, spl, X + (size_t)m * tb.ld, tid);
 }
 
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s)
@@ -138,8 +171,9 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(FftTables tb, const f
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<true>(tb.tw1024, tid);
+    const SplitCtx spl = load_split(tb, tid, true);
     const size_t m = blockIdx.x;
-    irfft_merge(Y + m * tb.ld, tb.tw2048, z0, tb.colmap, tid);
+    irfft_merge<false>(Y + m * tb.ld, spl, z0, tid);
     __syncthreads();
     const float2* z = fft1024<true>(z0, z1, twd, tid);
     float* dst = frames + m * NFFT;
@@ -239,6 +273,7 @@ __global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, floa
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<false>(tb.tw1024, tid);
+    const SplitCtx spl = load_split(tb, tid, false);
     const int c = blockIdx.x;
     float* b = buf + (size_t)c * NFFT;
     const float* ch = chunk + (size_t)c * HOPS;
@@ -261,7 +296,7 @@ __global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, floa
     }
     __syncthreads();
     const float2* Z = fft1024<false>(z0, z1, twd, tid);
-    rfft_split_store(Z, tb.tw2048, X + (size_t)c * tb.ld, tb.colmap, tid);
+    rfft_split_store(Z, spl, X + (size_t)c * tb.ld, tid);
 }
 
 __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, const float* __restrict__ Y, const float* __restrict__ X,
@@ -272,6 +307,7 @@ __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, con
     __shared__ __attribute__((aligned(16))) float spec[F2 + 2];
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<true>(tb.tw1024, tid);
+    const SplitCtx spl = load_split(tb, tid, false);
     const int c = blockIdx.x;
     const float* y = Y + (size_t)c * tb.ld;
     const float* x = X + (size_t)c * tb.ld;
@@ -282,7 +318,7 @@ __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, con
         spec[i] = (mix == 1.f) ? y[col] : mix * y[col] + dry * x[col];
     }
     __syncthreads();
-    irfft_merge(spec, tb.tw2048, z0, nullptr, tid);
+    irfft_merge<true>(spec, spl, z0, tid);
     __syncthreads();
     const float2* z = fft1024<true>(z0, z1, twd, tid);
     float* pv = prev + (size_t)c * NFFT;
