@@ -1,0 +1,88 @@
+"""GPU edge cases against the oracle: minimum-length input (T = 2), a single row, odd row counts that
+do not fill any tile, the 41-band table through the recurrent / streaming entry points, and a long
+sequence checked through causality (chunked == offline)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def make_model(sd, v=None):
+    from speechseparation_amd.bsrnn import BSRNN
+    m = BSRNN(v).eval()
+    m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd.items()}, strict=True)
+    return m.to("cuda")
+
+
+def test_minimum_length_and_single_row(sd_default):
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    m = make_model(sd_default)
+    for rows, n in ((1, 1025), (1, 2047), (3, 2048), (5, 3000)):
+        wave = weights.synth_waveform(rows, n, seed=100 + n)
+        out = m.separate(torch.from_numpy(wave).cuda())
+        ref = onp.separate(sd_default, wave)
+        assert tuple(out.shape) == ref.shape == (rows, (n // 1024) * 1024)
+        assert maxabs(out.cpu().numpy(), ref) < TOL, (rows, n)
+
+
+def test_odd_shapes_forward_and_mask(sd_default):
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    m = make_model(sd_default)
+    x = onp.stft_interleaved(weights.synth_waveform(5, 2 * 1024 + 17, seed=77))       # [5, 2050, 3]
+    taps = {}
+    ref = onp.forward(sd_default, x, taps=taps)
+    y, mask = m.forward_with_mask(torch.from_numpy(x).cuda())
+    assert maxabs(y.cpu().numpy(), ref) < TOL and maxabs(mask.cpu().numpy(), taps["mask"]) < TOL
+    z = weights.synth_tensor((3, 2, 12, 64), seed=5, scale=0.4)
+    st = weights.synth_tensor((4, 2, 36, 64), seed=6, scale=0.3)
+    zr, sr = onp.dual_path(sd_default, z, st)
+    zo, so = m.dual_path(torch.from_numpy(z).cuda(), torch.from_numpy(st).cuda())
+    assert maxabs(zo.cpu().numpy(), zr) < 2e-5 and maxabs(so.cpu().numpy(), sr) < 2e-5
+
+
+def test_bands41_recurrent_and_streaming():
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import spec, weights
+    from speechseparation_amd.bsrnn import StreamingSeparator
+    v = spec.variant_bandsplits("41")
+    sd = weights.synth_state_dict(v, seed=3)
+    m = make_model(sd, v)
+    K = len(v)
+    x = onp.stft_interleaved(weights.synth_waveform(2, 3 * 1024, seed=9))              # [2, 2050, 4]
+    state = weights.synth_tensor((4, 2, 2 * K, 64), seed=11, scale=0.2)
+    yr, sr = onp.forward_recurrent(sd, x[:, :, 1], state, v)
+    y, s = m.forward_recurrent(torch.from_numpy(np.ascontiguousarray(x[:, :, 1])).cuda(), torch.from_numpy(state).cuda())
+    assert maxabs(y.cpu().numpy(), yr) < TOL and maxabs(s.cpu().numpy(), sr) < 2e-5
+    st = StreamingSeparator(m, channels=2)
+    so = onp.StreamingOracle(sd, C=2, v=v)
+    wave = weights.synth_waveform(2, 3 * 1024, seed=12)
+    for i in range(3):
+        c = wave[:, i * 1024:(i + 1) * 1024]
+        assert maxabs(st.step(torch.from_numpy(c.copy()).cuda()).cpu().numpy(), so.step(c)) < TOL
+
+
+def test_long_sequence_causality(sd_default):
+    """T = 400 frames (about 9.5 s at 44.1 kHz): arbitrary chunkings with state carry equal the
+    offline forward; the state after the whole sequence is independent of the chunking."""
+    from speechseparation_amd import weights
+    m = make_model(sd_default)
+    x = m.stft(torch.from_numpy(weights.synth_waveform(2, 399 * 1024 + 5, seed=21)).cuda())   # [2, 2050, 400]
+    y_off = m(x)
+    finals = []
+    for cuts in ((0, 400), (0, 1, 257, 400), (0, 100, 200, 300, 400)):
+        state = torch.zeros((4, 2, 24, 64), device="cuda")
+        ys = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            y, state = m.forward_chunk(x[:, :, a:b].contiguous(), state)
+            ys.append(y)
+        assert maxabs(torch.cat(ys, 2).cpu().numpy(), y_off.cpu().numpy()) < 3e-5
+        finals.append(state.cpu().numpy())
+    assert maxabs(finals[0], finals[1]) < 2e-5 and maxabs(finals[0], finals[2]) < 2e-5
