@@ -21,6 +21,8 @@
 // a ds_read_b128 lane group hit 16 distinct 16-byte slots.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace bsrnn {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -256,6 +258,201 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
     }
 }
 
+// =====================================================================================
+// fp32-accurate GEMM on the bf16 matrix cores ("bf16x3"): every fp32 operand is split exactly into three
+// bf16 pieces a = a1 + a2 + a3 (8 significant bits each, residuals are exact in fp32), and a.b is
+// evaluated as the six bf16 MFMA terms of weight >= 2^-16,
+//     a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2),
+// with fp32 accumulation (products of bf16 pairs are exact in fp32).  The dropped terms are <= 2^-23
+// relative, i.e. the result is as accurate as an fp32 fma chain, at 6/16 of the fp32-MFMA pipe time
+// (v_mfma_f32_32x32x16_bf16: 16x the MACs per cycle of v_mfma_f32_32x32x2_f32).  The large term has its own
+// accumulator so the small corrections are summed among themselves before they meet it.
+// Same tiling (128 x 64 x 32, 4 waves as 2 x 2), XCD mapping, and LDS-staged epilogue as the fp32 kernel;
+// operands are split by the staging threads on their way into LDS (three bf16 planes, rows padded to
+// 80 bytes: conflict-free ds_read_b128 fragments).
+// =====================================================================================
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(const v4f a, bf16x4& p1, bf16x4& p2, bf16x4& p3)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p1[i] = (__bf16)a[i];
+        const float r1 = a[i] - (float)p1[i];
+        p2[i] = (__bf16)r1;
+        const float r2 = r1 - (float)p2[i];
+        p3[i] = (__bf16)r2;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmLaunch g)
+{
+    constexpr int BN = 64;
+    constexpr int PS = 40;                          // plane row stride in bf16 (80 bytes: 32 data + 8 pad)
+    constexpr int PLANE = (BM + BN) * PS;           // one plane: A rows then B rows
+    typedef const v4f __attribute__((address_space(1)))* gcf4;
+    __shared__ __attribute__((aligned(16))) __bf16 smemh[3 * PLANE];
+    static_assert(3 * PLANE * 2 >= 64 * (BN + 4) * 4, "epilogue staging must fit");
+
+    const int m_tiles = (g.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
+    const int mchunk = g.mchunk;
+    const int per_chunk = mchunk * g.n_tiles;
+    const int chunk = (lidx / per_chunk) * 8 + xcd;
+    const int rem = lidx % per_chunk;
+    const int m_tile = chunk * mchunk + rem % mchunk;
+    if (m_tile >= m_tiles) return;
+    const int2 tj = g.tiles[rem / mchunk];
+    const GemmJob job = g.jobs[tj.x];
+    const int n0 = tj.y * BN;
+    const int m0 = m_tile * BM;
+    const int N = job.N, K = job.K, M = g.M;
+    const gcf X = (gcf)(g.X + job.x_off);
+    const gcf W = (gcf)job.W;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, r32 = lane & 31;
+    const int ncol = n0 + 32 * wn + r32;
+    const float bias = ((gcf)job.bias)[ncol < N ? ncol : N - 1];
+    const bool wave_live = (n0 + 32 * wn) < N;
+
+    // staging: float4 units, 8 per 32-float row, 32 rows per pass
+    const int s_row = tid >> 3, s_k = (tid & 7) * 4;
+    unsigned oa[4], ob[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = m0 + s_row + 32 * i;
+        row = row < M ? row : M - 1;
+        oa[i] = (unsigned)row * (unsigned)g.ldx + s_k;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = n0 + s_row + 32 * i;
+        row = row < N ? row : N - 1;
+        ob[i] = (unsigned)row * (unsigned)K + s_k;
+    }
+    v4f ra[4], rb[2];
+    auto gload = [&](int k0) {
+        const bool kin = k0 + s_k < K;              // K is a multiple of 4: a unit is fully in or out
+        const int kk = kin ? k0 : -s_k;
+        const float zm = kin ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + kk)) * zm;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i] = *(gcf4)(W + (ob[i] + kk)) * zm;
+    };
+
+    v16f hi[2], lo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { hi[i] = (v16f){0}; lo[i] = (v16f){0}; }
+
+    if (K > 0) gload(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 p1, p2, p3;
+            split3(ra[i], p1, p2, p3);
+            const int o = (s_row + 32 * i) * PS + s_k;
+            *reinterpret_cast<bf16x4*>(&smemh[o]) = p1;
+            *reinterpret_cast<bf16x4*>(&smemh[PLANE + o]) = p2;
+            *reinterpret_cast<bf16x4*>(&smemh[2 * PLANE + o]) = p3;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x4 p1, p2, p3;
+            split3(rb[i], p1, p2, p3);
+            const int o = (BM + s_row + 32 * i) * PS + s_k;
+            *reinterpret_cast<bf16x4*>(&smemh[o]) = p1;
+            *reinterpret_cast<bf16x4*>(&smemh[PLANE + o]) = p2;
+            *reinterpret_cast<bf16x4*>(&smemh[2 * PLANE + o]) = p3;
+        }
+        __syncthreads();
+        if (k0 + 32 < K) gload(k0 + 32);
+        if (!wave_live) continue;
+        __builtin_amdgcn_s_setprio(1);
+        // bf16 32x32x16 operand maps: lane (r = l & 31, h = l >> 5) holds A[r][8h .. 8h+7] / B[8h .. 8h+7][r]
+        const int oa0 = (64 * wm + r32) * PS + 8 * half;
+        const int ob0 = (BM + 32 * wn + r32) * PS + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 b[3], a[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                b[pl] = *reinterpret_cast<const bf16x8*>(&smemh[pl * PLANE + ob0 + 16 * ks]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(&smemh[pl * PLANE + oa0 + 32 * i * PS + 16 * ks]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], lo[i], 0, 0, 0);
+                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], lo[i], 0, 0, 0);
+                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], lo[i], 0, 0, 0);
+                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], lo[i], 0, 0, 0);
+                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], lo[i], 0, 0, 0);
+                hi[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], hi[i], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // epilogue through LDS, identical to the fp32 kernel
+    constexpr int ES = BN + 4;
+    float* const sE = reinterpret_cast<float*>(smemh);
+    const int my_col = 32 * wn + r32;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        __syncthreads();
+        if (wm == hh && wave_live) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float v = (hi[i][reg] + lo[i][reg]) + bias;
+                    if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
+                    sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + my_col] = v;
+                }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 4;
+#pragma unroll
+        for (int u = 0; u < 64 * CPR / 256; ++u) {
+            const int idx = tid + 256 * u;
+            const int row = idx / CPR, c4 = idx % CPR;
+            const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
+            if (m < M && n < N) {
+                v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
+                if (EPI == EPI_RES || EPI == EPI_MASK)
+                    v += *reinterpret_cast<const v4f __attribute__((address_space(1)))*>((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
+                if (EPI == EPI_MASK) {
+                    if (g.tap) *reinterpret_cast<v4f __attribute__((address_space(1)))*>((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
+                    v *= *reinterpret_cast<const v4f __attribute__((address_space(1)))*>((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
+                }
+                *reinterpret_cast<v4f __attribute__((address_space(1)))*>((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
+            }
+        }
+    }
+}
+
+static void launch_gemm_bf16x3(const GemmLaunch& g_in, hipStream_t stream)
+{
+    GemmLaunch g = g_in;
+    const int m_tiles = (g.M + BM - 1) / BM;
+    g.mchunk = gemm_mchunk(m_tiles);
+    const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
+    dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(256);
+    switch (g.epilogue) {
+    case EPI_LINEAR: hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI_LINEAR>, grid, block, 0, stream, g); break;
+    case EPI_LEAKY:  hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI_LEAKY>, grid, block, 0, stream, g); break;
+    case EPI_RES:    hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI_RES>, grid, block, 0, stream, g); break;
+    default:         hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI_MASK>, grid, block, 0, stream, g); break;
+    }
+}
+
 template <int NT, int ABL, int PRIO = 0, int VEC = 2>
 static void launch_gemm_nt(const GemmLaunch& g_in, hipStream_t stream)
 {
@@ -278,6 +475,8 @@ void launch_gemm(const GemmLaunch& g, hipStream_t stream)
     if (g.M <= 0 || g.n_tiles <= 0) return;
     // PRIO = 1 (s_setprio around the MFMA cluster) measured +3..5 % on the 64-wide kernel, 0 on the 128-wide
     // every job is 16-byte aligned (band-padded layouts, weight rows padded to multiples of 4): dwordx4 loads
+    static const int use_split = [] { const char* e = getenv("BSRNN_GEMM_BF16X3"); return e ? atoi(e) : 0; }();
+    if (use_split && g.tile_n == 64) { launch_gemm_bf16x3(g, stream); return; }
     if (g.tile_n == 128)
         launch_gemm_nt<2, 0, 0, 4>(g, stream);
     else
