@@ -4,6 +4,7 @@
 // There is no CPU compute path here: every entry point either enqueues HIP kernels or fails.
 #include "../../include/bsrnn_hip.h"
 #include "kernels.h"
+#include "split_host.h"
 
 #include <algorithm>
 #include <cmath>
@@ -144,7 +145,7 @@ void add_linear(bsrnn_ctx* c, const std::string& prefix, int n_out, int n_in)
     add_param(c, prefix + ".bias", n_out, 0, 1);
 }
 int imax(int a, int b) { return a > b ? a : b; }
-int round4(int a) { return (a + 3) & ~3; }
+int round8(int a) { return (a + 7) & ~7; }
 
 // parameter inventory in the reference's state_dict order (bsrnn.py:329-376)
 void build_inventory(bsrnn_ctx* c)
@@ -292,6 +293,8 @@ void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ld
                const float* Mul, int ldm, float* tap, int M, int epi, hipStream_t s)
 {
     GemmLaunch g;
+    memset(&g, 0, sizeof g);
+    g.out_mode = 1;
     g.jobs = c->d_jobs + c->job0[slot];
     g.tiles = c->d_tiles + c->tile0[slot];
     g.n_tiles = c->ntiles[slot];
@@ -444,10 +447,10 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
     int pos = 0, ao = 0, po = 0;
     for (int i = 0; i < n_bands; ++i) {
         c->off.push_back(pos); pos += widths[i];
-        c->aoff.push_back(ao); ao += round4(imax(2 * widths[i], 2 * HID));
-        c->poff.push_back(po); po += round4(2 * widths[i]);
+        c->aoff.push_back(ao); ao += round8(imax(2 * widths[i], 2 * HID));
+        c->poff.push_back(po); po += round8(2 * widths[i]);
     }
-    c->LDA = ao; c->LDP = imax(po, 4);
+    c->LDA = ao; c->LDP = imax(po, 8);
     build_inventory(c);
     if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(1, std::min(MAX_PARTS, atoi(e)));
     if (const char* e = getenv("BSRNN_PART_LAG")) c->part_lag = std::max(0, std::min((int)MS_COUNT, atoi(e)));
@@ -567,7 +570,17 @@ int bsrnn_commit_params(bsrnn_ctx* c)
 
     Arena ar;
     std::vector<GemmJob> jobs;
-    std::vector<size_t> jw, jb;          // arena offsets, patched to pointers after upload
+    std::vector<size_t> jw, jb, jwp;     // arena offsets, patched to pointers after upload
+    // split-precision modes: the same matrix as NP 16-bit planes [NP][N][Kp] (gemm.hip), packed into arena floats
+    const int gmode = gemm_mode();
+    auto put_planes = [&](const std::vector<float>& wp) -> size_t {
+        if (gmode == GEMM_F32 || wp.empty()) return 0;
+        std::vector<uint16_t> pl(wp.size() * gmode + 1);
+        split_planes_host(wp.data(), wp.size(), gmode, pl.data());
+        std::vector<float> packed((wp.size() * gmode + 1) / 2);
+        memcpy(packed.data(), pl.data(), wp.size() * gmode * sizeof(uint16_t));
+        return ar.put(packed);
+    };
     std::vector<int2> tiles;
     const int H = HID, K = c->K;
     char b[128];
@@ -578,14 +591,16 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         j.N = N; j.K = Kd; j.x_off = x_off; j.y_off = y_off; j.r_off = r_off; j.m_off = m_off;
         const Param& w = P_(c, std::string(prefix) + ".weight");
         const Param& bi = P_(c, std::string(prefix) + ".bias");
-        // weight rows padded with zeros to a multiple of 4 floats: every row is 16-byte aligned and the kernel's
-        // K loop runs over whole float4 units (the matching input pad columns are finite, see ensure_ws)
-        const int Kp = round4(Kd);
+        // weight rows padded with zeros to a multiple of 8: every row is 16-byte aligned in fp32 and in the 16-bit
+        // planes, and the kernels' K loops run over whole 16-byte units (the matching input pad columns are zero,
+        // see ensure_ws and the GEMM epilogue)
+        const int Kp = round8(Kd);
         j.K = Kp;
         std::vector<float> wp((size_t)N * Kp, 0.f);
         for (int r = 0; r < N; ++r) memcpy(&wp[(size_t)r * Kp], &w.data[(size_t)r * Kd], Kd * sizeof(float));
         jw.push_back(ar.put(wp));
         jb.push_back(ar.put(bi.data));
+        jwp.push_back(put_planes(wp));
         jobs.push_back(j);
     };
     auto begin_slot = [&](int slot) { c->job0[slot] = (int)jobs.size(); c->tile0[slot] = (int)tiles.size(); };
@@ -600,7 +615,9 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         // 128-wide tiles pay off only when the launch has many more workgroups than CU slots (uniform
         // large GEMMs: 114 vs 99 TFLOP/s); at M = C*T ~ 8k rows the 64-wide tiling balances the ragged
         // per-band costs better (measured 2.75 vs 2.79 ms per step), so it is the default.
-        const int tn = (maxn > 64 && getenv("BSRNN_GEMM_TILE128")) ? 128 : 64;
+        // The split-precision kernels do 2-3x less matrix-pipe work per tile and are bound by the CU's load
+        // path instead: there the 128-wide tile (2/3 of the bytes per flop) wins (tools/gemm_planes_bench.hip).
+        const int tn = (maxn > 64 && (gmode != GEMM_F32 || getenv("BSRNN_GEMM_TILE128"))) ? 128 : 64;
         c->tile_n[slot] = tn;
         std::vector<int> order;
         for (int ji = j0; ji < (int)jobs.size(); ++ji) order.push_back(ji);
@@ -625,7 +642,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
                     j.N = H; j.K = 0; j.y_off = i * H;
                     snprintf(b, sizeof b, "bandFCs.%d.0.trainable_constant", i);
                     const Param& cst = P_(c, b);
-                    jw.push_back(ar.put(cst.data)); jb.push_back(ar.put(cst.data));
+                    jw.push_back(ar.put(cst.data)); jb.push_back(ar.put(cst.data)); jwp.push_back(0);
                     jobs.push_back(j);
                 }
                 continue;
@@ -699,7 +716,10 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     if (c->d_tiles) { HIP_TRY(hipFree(c->d_tiles)); c->d_tiles = nullptr; }
     HIP_TRY(hipMalloc((void**)&c->d_arena, (ar.h.size() + 4) * sizeof(float)));
     HIP_TRY(hipMemcpy(c->d_arena, ar.h.data(), ar.h.size() * sizeof(float), hipMemcpyHostToDevice));
-    for (size_t i = 0; i < jobs.size(); ++i) { jobs[i].W = c->d_arena + jw[i]; jobs[i].bias = c->d_arena + jb[i]; }
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        jobs[i].W = c->d_arena + jw[i]; jobs[i].bias = c->d_arena + jb[i];
+        jobs[i].Wp = c->d_arena + jwp[i];
+    }
     HIP_TRY(hipMalloc((void**)&c->d_jobs, jobs.size() * sizeof(GemmJob)));
     HIP_TRY(hipMemcpy(c->d_jobs, jobs.data(), jobs.size() * sizeof(GemmJob), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&c->d_tiles, tiles.size() * sizeof(int2)));

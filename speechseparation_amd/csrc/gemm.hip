@@ -21,7 +21,9 @@
 // a ds_read_b128 lane group hit 16 distinct 16-byte slots.
 #include "kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace bsrnn {
 
@@ -259,42 +261,78 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
 }
 
 // =====================================================================================
-// fp32-accurate GEMM on the bf16 matrix cores ("bf16x3"): every fp32 operand is split exactly into three
-// bf16 pieces a = a1 + a2 + a3 (8 significant bits each, residuals are exact in fp32), and a.b is
-// evaluated as the six bf16 MFMA terms of weight >= 2^-16,
-//     a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2),
-// with fp32 accumulation (products of bf16 pairs are exact in fp32).  The dropped terms are <= 2^-23
-// relative, i.e. the result is as accurate as an fp32 fma chain, at 6/16 of the fp32-MFMA pipe time
-// (v_mfma_f32_32x32x16_bf16: 16x the MACs per cycle of v_mfma_f32_32x32x2_f32).  The large term has its own
-// accumulator so the small corrections are summed among themselves before they meet it.
-// Same tiling (128 x 64 x 32, 4 waves as 2 x 2), XCD mapping, and LDS-staged epilogue as the fp32 kernel;
-// operands are split by the staging threads on their way into LDS (three bf16 planes, rows padded to
-// 80 bytes: conflict-free ds_read_b128 fragments).
+// Split-precision kernel.  fp32 operands are represented as NP low-precision pieces and the product is evaluated
+// on the 16-bit matrix cores (16x the MACs per cycle of v_mfma_f32_32x32x2_f32) with fp32 accumulation:
+//   NP = 3 (bf16x3): a = a1 + a2 + a3 exactly (8 significant bits each, the residuals are exact in fp32); the six
+//          terms of weight >= 2^-16, a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2); the dropped ones are <= 2^-24.
+//   NP = 2 (fp16x2): a ~ a1 + 2^-11 a2 with a1 = fp16(a), a2 = fp16(2^11 (a - a1)) - 22 significant bits, i.e.
+//          2^-23 relative representation error per operand, the level of fp32 accumulation noise.  Three MFMA
+//          terms: hi += a1 b1;  lo += a1 b2 + a2 b1;  result = hi + 2^-11 lo  (a2 b2 ~ 2^-22 is dropped).
+//          The 2^11 scaling keeps a2 out of the fp16 subnormal range for |a| >= 2^-14; |a| is clamped to the
+//          fp16 maximum 65504 (the model's activations and weights are O(1); a value beyond that would saturate).
+//          (Scheme: Ootomo & Yokota, "Recovering single precision accuracy from Tensor Cores...", 2022.)
+// Same XCD-aware work mapping and LDS-staged epilogue as the fp32 kernel; the pieces sit in LDS as NP planes
+// with 80-byte rows (conflict-free ds_read_b128 fragments).  Measured limits (tools/gemm_planes_bench.hip) are the
+// CU's global-load path and the per-slab barrier pairs, not the MFMA pipe, hence:
+//   * NT = 2: 128 x 128 tile, four waves of 64 x 64;
+//   * BMODE 1: weights arrive already split (GemmJob::Wp, NP planes made once on the host);  0: split on the fly;
+//   * AMODE 1: activations arrive as NP planes too (written by the producing layer's epilogue, out_mode & 2);
+//     0: fp32 activations are split by the staging threads;
+//   * ACC2: separate accumulators for the leading term and the corrections (required for NP = 2);
+//   * PF: slabs in flight (register staging sets).
+// ABL (measurement only): 1 = no global loads after the first slab, 2 = no MFMA.
 // =====================================================================================
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3(const v4f a, bf16x4& p1, bf16x4& p2, bf16x4& p3)
-{
+template <int NP> struct Piece;
+template <> struct Piece<3> {
+    typedef __bf16 T;
+    typedef __bf16 T4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 T8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void split(const v4f a, T4* p)
+    {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        p1[i] = (__bf16)a[i];
-        const float r1 = a[i] - (float)p1[i];
-        p2[i] = (__bf16)r1;
-        const float r2 = r1 - (float)p2[i];
-        p3[i] = (__bf16)r2;
+        for (int i = 0; i < 4; ++i) {
+            p[0][i] = (__bf16)a[i];
+            const float r1 = a[i] - (float)p[0][i];
+            p[1][i] = (__bf16)r1;
+            p[2][i] = (__bf16)(r1 - (float)p[1][i]);
+        }
     }
-}
+    static __device__ __forceinline__ v16f mfma(const T8 a, const T8 b, const v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Piece<2> {
+    typedef _Float16 T;
+    typedef _Float16 T4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 T8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void split(const v4f a, T4* p)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float c = __builtin_fminf(__builtin_fmaxf(a[i], -65504.f), 65504.f);
+            p[0][i] = (_Float16)c;
+            p[1][i] = (_Float16)((c - (float)p[0][i]) * 2048.f);
+        }
+    }
+    static __device__ __forceinline__ v16f mfma(const T8 a, const T8 b, const v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmLaunch g)
+template <int EPI, int NP, int NT, int AMODE, int BMODE, int ACC2, int PF = 1, int ABL = 0>
+__global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(GemmLaunch g)
 {
-    constexpr int BN = 64;
-    constexpr int PS = 40;                          // plane row stride in bf16 (80 bytes: 32 data + 8 pad)
+    static_assert(NP == 3 || ACC2 == 1, "fp16x2 keeps the scaled corrections in their own accumulator");
+    typedef Piece<NP> PC;
+    typedef typename PC::T hT;
+    typedef typename PC::T4 h4;
+    typedef typename PC::T8 h8;
+    typedef const h8 __attribute__((address_space(1)))* gch8;
+    typedef h8 __attribute__((address_space(1)))* gh8;
+    typedef const hT __attribute__((address_space(1)))* gch;
+    constexpr int BN = 64 * NT;
+    constexpr int PS = 40;                          // plane row stride in 16-bit elements (80 bytes: 64 data + 16 pad)
     constexpr int PLANE = (BM + BN) * PS;           // one plane: A rows then B rows
+    constexpr int ES = BN + 4;                      // epilogue staging row stride (floats)
+    constexpr int NACC = ACC2 ? 2 : 1;
     typedef const v4f __attribute__((address_space(1)))* gcf4;
-    __shared__ __attribute__((aligned(16))) __bf16 smemh[3 * PLANE];
-    static_assert(3 * PLANE * 2 >= 64 * (BN + 4) * 4, "epilogue staging must fit");
+    __shared__ __attribute__((aligned(16))) hT smemh[(NP * PLANE * 2 >= 64 * ES * 4) ? NP * PLANE : 64 * ES * 2];
 
     const int m_tiles = (g.M + BM - 1) / BM;
     const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
@@ -308,137 +346,264 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmLaunch g)
     const GemmJob job = g.jobs[tj.x];
     const int n0 = tj.y * BN;
     const int m0 = m_tile * BM;
-    const int N = job.N, K = job.K, M = g.M;
-    const gcf X = (gcf)(g.X + job.x_off);
-    const gcf W = (gcf)job.W;
+    const int N = job.N, K = job.K, M = g.M;       // K is a multiple of 8 (zero-padded weights, zero pad columns)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, r32 = lane & 31;
-    const int ncol = n0 + 32 * wn + r32;
-    const float bias = ((gcf)job.bias)[ncol < N ? ncol : N - 1];
-    const bool wave_live = (n0 + 32 * wn) < N;
+    const int wcol = 32 * NT * wn;                 // first column of this wave inside the tile
+    float bias[NT];
+    bool live[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nc = n0 + wcol + 32 * j + r32;
+        bias[j] = ((gcf)job.bias)[nc < N ? nc : N - 1];
+        live[j] = (n0 + wcol + 32 * j) < N;
+    }
 
-    // staging: float4 units, 8 per 32-float row, 32 rows per pass
+    // staging in 16-byte units.  16-bit planes: 4 units per 32-deep row, 64 rows per pass of the 256 threads;
+    // fp32: 8 units per row, 32 rows per pass.
+    const int p_row = tid >> 2, p_k = (tid & 3) * 8;
     const int s_row = tid >> 3, s_k = (tid & 7) * 4;
-    unsigned oa[4], ob[2];
+    const gch Wp = (gch)job.Wp;
+    const unsigned wplane = (unsigned)N * (unsigned)K;
+    const gcf W = (gcf)job.W;
+    const gch Xp = (gch)g.Xp + job.x_off;
+    const gcf X = (gcf)(g.X + job.x_off);
+    unsigned oap[2], oa[4], obp[NT], ob[2 * NT];
+    // register staging sets: PF slabs are in flight (the loads of slab k + PF are issued before the MFMAs of slab k)
+    struct Stage { v4f ra[4]; v4f rb[2 * NT]; h8 rap[2][NP]; h8 rbp[NT][NP]; };
+    Stage st[PF];
+    if (AMODE == 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int row = m0 + s_row + 32 * i;
-        row = row < M ? row : M - 1;
-        oa[i] = (unsigned)row * (unsigned)g.ldx + s_k;
+        for (int i = 0; i < 2; ++i) { int row = m0 + p_row + 64 * i; row = row < M ? row : M - 1; oap[i] = (unsigned)row * (unsigned)g.ldx + p_k; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { int row = m0 + s_row + 32 * i; row = row < M ? row : M - 1; oa[i] = (unsigned)row * (unsigned)g.ldx + s_k; }
     }
+    if (BMODE == 1) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int row = n0 + s_row + 32 * i;
-        row = row < N ? row : N - 1;
-        ob[i] = (unsigned)row * (unsigned)K + s_k;
+        for (int i = 0; i < NT; ++i) { int row = n0 + p_row + 64 * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * (unsigned)K + p_k; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) { int row = n0 + s_row + 32 * i; row = row < N ? row : N - 1; ob[i] = (unsigned)row * (unsigned)K + s_k; }
     }
-    v4f ra[4], rb[2];
-    auto gload = [&](int k0) {
-        const bool kin = k0 + s_k < K;              // K is a multiple of 4: a unit is fully in or out
-        const int kk = kin ? k0 : -s_k;
-        const float zm = kin ? 1.f : 0.f;
+    // full slabs take plain loads: any arithmetic on the loaded registers here (tail masking) would make the
+    // compiler wait for the loads right away, in front of the MFMA cluster they are meant to overlap with
+    auto gload = [&](Stage& t, int k0) {
+        if (k0 + 32 <= K) {
+            if (BMODE == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + kk)) * zm;
+                for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) rb[i] = *(gcf4)(W + (ob[i] + kk)) * zm;
-    };
-
-    v16f hi[2], lo[2];
+                    for (int pl = 0; pl < NP; ++pl) t.rbp[i][pl] = *(gch8)(Wp + (obp[i] + k0 + pl * wplane));
+            } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { hi[i] = (v16f){0}; lo[i] = (v16f){0}; }
-
-    if (K > 0) gload(0);
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x4 p1, p2, p3;
-            split3(ra[i], p1, p2, p3);
-            const int o = (s_row + 32 * i) * PS + s_k;
-            *reinterpret_cast<bf16x4*>(&smemh[o]) = p1;
-            *reinterpret_cast<bf16x4*>(&smemh[PLANE + o]) = p2;
-            *reinterpret_cast<bf16x4*>(&smemh[2 * PLANE + o]) = p3;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bf16x4 p1, p2, p3;
-            split3(rb[i], p1, p2, p3);
-            const int o = (BM + s_row + 32 * i) * PS + s_k;
-            *reinterpret_cast<bf16x4*>(&smemh[o]) = p1;
-            *reinterpret_cast<bf16x4*>(&smemh[PLANE + o]) = p2;
-            *reinterpret_cast<bf16x4*>(&smemh[2 * PLANE + o]) = p3;
-        }
-        __syncthreads();
-        if (k0 + 32 < K) gload(k0 + 32);
-        if (!wave_live) continue;
-        __builtin_amdgcn_s_setprio(1);
-        // bf16 32x32x16 operand maps: lane (r = l & 31, h = l >> 5) holds A[r][8h .. 8h+7] / B[8h .. 8h+7][r]
-        const int oa0 = (64 * wm + r32) * PS + 8 * half;
-        const int ob0 = (BM + 32 * wn + r32) * PS + 8 * half;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 b[3], a[2][3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                b[pl] = *reinterpret_cast<const bf16x8*>(&smemh[pl * PLANE + ob0 + 16 * ks]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(&smemh[pl * PLANE + oa0 + 32 * i * PS + 16 * ks]);
+                for (int i = 0; i < 2 * NT; ++i) t.rb[i] = *(gcf4)(W + (ob[i] + k0));
             }
+            if (AMODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], lo[i], 0, 0, 0);
-                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], lo[i], 0, 0, 0);
-                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], lo[i], 0, 0, 0);
-                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], lo[i], 0, 0, 0);
-                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], lo[i], 0, 0, 0);
-                hi[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], hi[i], 0, 0, 0);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) t.rap[i][pl] = *(gch8)(Xp + pl * g.xp_plane + (oap[i] + k0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t.ra[i] = *(gcf4)(X + (oa[i] + k0));
             }
+            return;
         }
-        __builtin_amdgcn_s_setprio(0);
-    }
-
-    // epilogue through LDS, identical to the fp32 kernel
-    constexpr int ES = BN + 4;
-    float* const sE = reinterpret_cast<float*>(smemh);
-    const int my_col = 32 * wn + r32;
+        const bool pin = k0 + p_k < K, sin = k0 + s_k < K;      // a 16-byte unit is fully inside K or fully outside
+        const int pk = pin ? k0 : -p_k, sk = sin ? k0 : -s_k;
+        const float zm = sin ? 1.f : 0.f;
+        if (BMODE == 1) {
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        __syncthreads();
-        if (wm == hh && wave_live) {
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    t.rbp[i][pl] = *(gch8)(Wp + (obp[i] + pk + pl * wplane));
+                    if (!pin) t.rbp[i][pl] = (h8){0};
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) t.rb[i] = *(gcf4)(W + (ob[i] + sk)) * zm;
+        }
+        if (AMODE == 1) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    float v = (hi[i][reg] + lo[i][reg]) + bias;
-                    if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
-                    sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + my_col] = v;
+                for (int pl = 0; pl < NP; ++pl) {
+                    t.rap[i][pl] = *(gch8)(Xp + pl * g.xp_plane + (oap[i] + pk));
+                    if (!pin) t.rap[i][pl] = (h8){0};
                 }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.ra[i] = *(gcf4)(X + (oa[i] + sk)) * zm;
+        }
+    };
+    auto put_split = [&](const v4f v, int o) {
+        h4 p[NP];
+        PC::split(v, p);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<h4*>(&smemh[pl * PLANE + o]) = p[pl];
+    };
+    auto put = [&](const Stage& t) {
+        if (AMODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    *reinterpret_cast<h8*>(&smemh[pl * PLANE + (p_row + 64 * i) * PS + p_k]) = t.rap[i][pl];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) put_split(t.ra[i], (s_row + 32 * i) * PS + s_k);
+        }
+        if (BMODE == 1) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    *reinterpret_cast<h8*>(&smemh[pl * PLANE + (BM + p_row + 64 * i) * PS + p_k]) = t.rbp[i][pl];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) put_split(t.rb[i], (BM + s_row + 32 * i) * PS + s_k);
+        }
+    };
+
+    v16f acc[2][NT][NACC];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[i][j][a] = (v16f){0};
+
+    // 16-bit 32x32x16 operand maps: lane (r = l & 31, h = l >> 5) holds A[r][8h .. 8h+7] / B[8h .. 8h+7][r]
+    const int oa0 = (64 * wm + r32) * PS + 8 * half;
+    const int ob0 = (BM + wcol + r32) * PS + 8 * half;
+    auto compute = [&]() {
+        if (!live[0]) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 b[NT][NP], a[2][NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j][pl] = *reinterpret_cast<const h8*>(&smemh[pl * PLANE + ob0 + 32 * j * PS + 16 * ks]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i][pl] = *reinterpret_cast<const h8*>(&smemh[pl * PLANE + oa0 + 32 * i * PS + 16 * ks]);
+            }
+            if (ABL & 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) { acc[i][0][0][pl] += (float)a[i][pl][0]; acc[i][NT - 1][0][3 + pl] += (float)b[NT - 1][pl][1]; }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (j > 0 && !live[j]) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    v16f& lo = acc[i][j][NACC - 1];
+                    v16f& hi = acc[i][j][0];
+                    if (NP == 3) {
+                        lo = PC::mfma(a[i][NP - 1], b[j][0], lo);
+                        lo = PC::mfma(a[i][0], b[j][NP - 1], lo);
+                        lo = PC::mfma(a[i][1], b[j][1], lo);
+                    }
+                    lo = PC::mfma(a[i][1], b[j][0], lo);
+                    lo = PC::mfma(a[i][0], b[j][1], lo);
+                    hi = PC::mfma(a[i][0], b[j][0], hi);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (32 * u < K) gload(st[u], 32 * u);
+    for (int k0 = 0; k0 < K; k0 += 32 * PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kk = k0 + 32 * u;
+            if (u > 0 && kk >= K) break;
+            __syncthreads();
+            put(st[u]);
+            __syncthreads();
+            if (!(ABL & 1) && kk + 32 * PF < K) gload(st[u], kk + 32 * PF);
+            compute();
+        }
+    }
+
+    // epilogue through LDS in units of 8 columns: fp32 rows (two 16-byte stores) and / or the NP planes of the
+    // same 8 values (one 16-byte store per plane)
+    float* const sE = reinterpret_cast<float*>(smemh);
+    typedef const v4f __attribute__((address_space(1)))* gc4;
+    typedef v4f __attribute__((address_space(1)))* g4;
+    constexpr float LO_SCALE = NP == 2 ? 1.f / 2048.f : 1.f;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        __syncthreads();
+        if (wm == hh) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!live[j]) continue;
+                const int col = wcol + 32 * j + r32;
+                const bool in = n0 + col < N;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float v = (ACC2 ? acc[i][j][0][reg] + LO_SCALE * acc[i][j][NACC - 1][reg] : acc[i][j][0][reg]) + bias[j];
+                        if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
+                        if (!in) v = 0.f;               // pad columns of the output segment stay exactly zero
+                        sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + col] = v;
+                    }
+            }
         }
         __syncthreads();
-        constexpr int CPR = BN / 4;
+        constexpr int UPR = BN / 8;
 #pragma unroll
-        for (int u = 0; u < 64 * CPR / 256; ++u) {
+        for (int u = 0; u < 64 * UPR / 256; ++u) {
             const int idx = tid + 256 * u;
-            const int row = idx / CPR, c4 = idx % CPR;
-            const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
+            const int row = idx / UPR, c8 = idx % UPR;
+            const int m = m0 + 64 * hh + row, n = n0 + 8 * c8;
             if (m < M && n < N) {
-                v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
-                if (EPI == EPI_RES || EPI == EPI_MASK)
-                    v += *reinterpret_cast<const v4f __attribute__((address_space(1)))*>((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
-                if (EPI == EPI_MASK) {
-                    if (g.tap) *reinterpret_cast<v4f __attribute__((address_space(1)))*>((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
-                    v *= *reinterpret_cast<const v4f __attribute__((address_space(1)))*>((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
+                v4f v0 = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8]);
+                v4f v1 = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8 + 4]);
+                if (EPI == EPI_RES || EPI == EPI_MASK) {
+                    const gc4 r = (gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
+                    v0 += r[0]; v1 += r[1];
                 }
-                *reinterpret_cast<v4f __attribute__((address_space(1)))*>((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
+                if (EPI == EPI_MASK) {
+                    if (g.tap) { const g4 t = (g4)((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt); t[0] = v0; t[1] = v1; }
+                    const gc4 mu = (gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
+                    v0 *= mu[0]; v1 *= mu[1];
+                }
+                if (g.out_mode & 1) {
+                    const g4 y = (g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy);
+                    y[0] = v0; y[1] = v1;
+                }
+                if (g.out_mode & 2) {
+                    h4 pa[NP], pb[NP];
+                    PC::split(v0, pa);
+                    PC::split(v1, pb);
+                    typedef hT __attribute__((address_space(1)))* ghp;
+                    const ghp yp = (ghp)g.Yp + job.y_off + n + (size_t)m * g.ldy;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+                        *(gh8)(yp + pl * g.yp_plane) = __builtin_shufflevector(pa[pl], pb[pl], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             }
         }
     }
 }
 
-static void launch_gemm_bf16x3(const GemmLaunch& g_in, hipStream_t stream)
+template <int NP, int NT, int AMODE, int BMODE, int ACC2, int PF = 1, int ABL = 0>
+static void launch_gemm_split(const GemmLaunch& g_in, hipStream_t stream)
 {
     GemmLaunch g = g_in;
     const int m_tiles = (g.M + BM - 1) / BM;
@@ -446,10 +611,10 @@ static void launch_gemm_bf16x3(const GemmLaunch& g_in, hipStream_t stream)
     const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
     dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(256);
     switch (g.epilogue) {
-    case EPI_LINEAR: hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI_LINEAR>, grid, block, 0, stream, g); break;
-    case EPI_LEAKY:  hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI_LEAKY>, grid, block, 0, stream, g); break;
-    case EPI_RES:    hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI_RES>, grid, block, 0, stream, g); break;
-    default:         hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI_MASK>, grid, block, 0, stream, g); break;
+    case EPI_LINEAR: hipLaunchKernelGGL((gemm_split_kernel<EPI_LINEAR, NP, NT, AMODE, BMODE, ACC2, PF, ABL>), grid, block, 0, stream, g); break;
+    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_split_kernel<EPI_LEAKY, NP, NT, AMODE, BMODE, ACC2, PF, ABL>), grid, block, 0, stream, g); break;
+    case EPI_RES:    hipLaunchKernelGGL((gemm_split_kernel<EPI_RES, NP, NT, AMODE, BMODE, ACC2, PF, ABL>), grid, block, 0, stream, g); break;
+    default:         hipLaunchKernelGGL((gemm_split_kernel<EPI_MASK, NP, NT, AMODE, BMODE, ACC2, PF, ABL>), grid, block, 0, stream, g); break;
     }
 }
 
@@ -470,13 +635,35 @@ static void launch_gemm_nt(const GemmLaunch& g_in, hipStream_t stream)
     }
 }
 
+int gemm_mode()
+{
+    static const int mode = [] {
+        const char* e = getenv("BSRNN_GEMM");
+        if (!e || !*e || !strcmp(e, "fp16x2")) return (int)GEMM_FP16X2;
+        if (!strcmp(e, "f32")) return (int)GEMM_F32;
+        if (!strcmp(e, "bf16x3")) return (int)GEMM_BF16X3;
+        fprintf(stderr, "bsrnn: unknown BSRNN_GEMM='%s' (f32 | fp16x2 | bf16x3), using fp16x2\n", e);
+        return (int)GEMM_FP16X2;
+    }();
+    return mode;
+}
+
 void launch_gemm(const GemmLaunch& g, hipStream_t stream)
 {
     if (g.M <= 0 || g.n_tiles <= 0) return;
-    // PRIO = 1 (s_setprio around the MFMA cluster) measured +3..5 % on the 64-wide kernel, 0 on the 128-wide
-    // every job is 16-byte aligned (band-padded layouts, weight rows padded to multiples of 4): dwordx4 loads
-    static const int use_split = [] { const char* e = getenv("BSRNN_GEMM_BF16X3"); return e ? atoi(e) : 0; }();
-    if (use_split && g.tile_n == 64) { launch_gemm_bf16x3(g, stream); return; }
+    switch (gemm_mode()) {
+    case GEMM_FP16X2:
+        if (g.tile_n == 128) launch_gemm_split<2, 2, 0, 1, 1, 1>(g, stream);
+        else launch_gemm_split<2, 1, 0, 1, 1, 1>(g, stream);
+        return;
+    case GEMM_BF16X3:
+        if (g.tile_n == 128) launch_gemm_split<3, 2, 0, 1, 0, 2>(g, stream);
+        else launch_gemm_split<3, 1, 0, 1, 0, 1>(g, stream);
+        return;
+    default: break;
+    }
+    // exact fp32 on the fp32 matrix pipe.  PRIO = 1 (s_setprio around the MFMA cluster) measured +3..5 % on the
+    // 64-wide kernel, 0 on the 128-wide; every job is 16-byte aligned (band-padded layouts, padded weight rows)
     if (g.tile_n == 128)
         launch_gemm_nt<2, 0, 0, 4>(g, stream);
     else

@@ -15,7 +15,8 @@ constexpr int F2 = 2050;      // interleaved re/im columns
 // One job = one nn.Linear of one band.  A launch runs every job of one "layer slot" of the
 // per-band MLP chains over all M = C*T frame rows.
 struct GemmJob {
-    const float* W;      // [N][K] row-major (torch Linear layout), device, 8-byte aligned rows
+    const float* W;      // [N][K] row-major (torch Linear layout), device, K padded to a multiple of 8 floats
+    const void* Wp;      // the same matrix split into three bf16 planes [3][N][K] (gemm.hip, "planes" kernel)
     const float* bias;   // [N]
     int N, K;            // K may be 0: y = bias (TrainableConstantModule, bsrnn.py:12-24)
     int x_off;           // column offset of the job's input inside an X row
@@ -44,8 +45,17 @@ struct GemmLaunch {
     float* tap; int ldt;     // optional mask tap (EPI_MASK), may be null
     int M;
     int epilogue;
+    // split-precision ("planes") kernel only: activations as three bf16 planes, plane p of an [M][ld] matrix
+    // starts p * plane elements after the first; columns use the same offsets and ld as X / Y
+    const void* Xp; size_t xp_plane;   // input planes; null: X is fp32 and is split on the fly
+    void* Yp; size_t yp_plane;         // output planes (written when out_mode & 2)
+    int out_mode;                      // bit 0: write fp32 Y, bit 1: write planes Yp
 };
 void launch_gemm(const GemmLaunch& g, hipStream_t stream);
+// How the Linear layers are evaluated (environment BSRNN_GEMM = f32 | fp16x2 | bf16x3, read once per process).
+// The value is the number of 16-bit planes GemmJob::Wp must hold (0: none).
+enum GemmMode { GEMM_F32 = 0, GEMM_FP16X2 = 2, GEMM_BF16X3 = 3 };
+int gemm_mode();
 constexpr int GEMM_BM = 128;
 
 // ------------------------------------------------------------------ dual-path LSTM kernels

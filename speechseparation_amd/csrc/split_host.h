@@ -1,0 +1,64 @@
+// Host-side counterparts of the split-precision operand formats of gemm.hip (weights are split once at commit
+// time; tools and tests use the same routines to build and to recombine planes).
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+namespace bsrnn {
+
+inline uint16_t bf16_from_float(float f)                 // round to nearest even
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fff + ((u >> 16) & 1);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_float(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+inline uint16_t f16_from_float(float f)                  // round to nearest even, subnormals kept, |f| <= 65504
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000);
+    const uint32_t ab = x & 0x7fffffffu;
+    if (ab >= 0x47800000u) return sign | 0x7c00;          // >= 65536: infinity (callers clamp first)
+    if (ab < 0x38800000u) {                               // below 2^-14: subnormal grid of 2^-24
+        float a; memcpy(&a, &ab, 4);
+        return sign | (uint16_t)std::nearbyintf(a * 16777216.f);
+    }
+    const uint32_t mant = ab & 0x7fffffu;
+    uint16_t h = (uint16_t)((((ab >> 23) - 112) << 10) | (mant >> 13));
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+    return sign | h;
+}
+inline float f16_to_float(uint16_t h)
+{
+    const int e = (h >> 10) & 31, m = h & 1023;
+    float v = e == 0 ? std::ldexp((float)m, -24) : (e == 31 ? INFINITY : std::ldexp((float)(1024 + m), e - 25));
+    return (h & 0x8000) ? -v : v;
+}
+
+// np = 3: bf16 pieces a = p0 + p1 + p2;  np = 2: fp16 pieces a ~ p0 + 2^-11 p1 (see gemm.hip).  planes: [np][n]
+inline void split_planes_host(const float* src, size_t n, int np, uint16_t* planes)
+{
+    for (size_t i = 0; i < n; ++i) {
+        if (np == 3) {
+            const float a = src[i];
+            const uint16_t p0 = bf16_from_float(a); const float r1 = a - bf16_to_float(p0);
+            const uint16_t p1 = bf16_from_float(r1); const float r2 = r1 - bf16_to_float(p1);
+            planes[i] = p0; planes[n + i] = p1; planes[2 * n + i] = bf16_from_float(r2);
+        } else {
+            const float a = std::fmin(std::fmax(src[i], -65504.f), 65504.f);
+            const uint16_t p0 = f16_from_float(a);
+            planes[i] = p0; planes[n + i] = f16_from_float((a - f16_to_float(p0)) * 2048.f);
+        }
+    }
+}
+inline float join_planes_host(const uint16_t* planes, size_t n, size_t i, int np)
+{
+    if (np == 3) return (bf16_to_float(planes[i]) + bf16_to_float(planes[n + i])) + bf16_to_float(planes[2 * n + i]);
+    return f16_to_float(planes[i]) + f16_to_float(planes[n + i]) * (1.f / 2048.f);
+}
+
+}  // namespace bsrnn
