@@ -75,6 +75,7 @@ struct bsrnn_ctx {
     int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT], tile_n[NSLOT];
 
     const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
+    const void* bandW16[2][2];                     // fp16x2 pieces in MFMA operand order (lstm.hip)
     float* d_tables = nullptr;
     int* d_colmap = nullptr;
     FftTables tb;
@@ -354,8 +355,8 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     case MS_BAND0: case MS_BAND1: {   // BandwiseLSTM: N = M sequences of length K   bsrnn.py:138-153
         const int blk = stage == MS_BAND1;
         StageScope sc(c, ST_BAND_LSTM, s);
-        launch_band_lstm(p.Z0, p.HB0, c->bandW[blk][0], c->bandB[blk][0], M, K, 64, s);
-        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandB[blk][1], M, K, 128, s);
+        launch_band_lstm(p.Z0, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, s);
+        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, s);
         break;
     }
     case MS_BANDFC0: case MS_BANDFC1: {
@@ -672,15 +673,31 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     }
 
     // LSTM weights, folded and packed in the kernels' register order (lstm.hip)
-    size_t o_bandW[2][2], o_bandB[2][2], o_timeW[2], o_timeB[2];
+    size_t o_bandW[2][2], o_bandW16[2][2], o_bandB[2][2], o_timeW[2], o_timeB[2];
     std::vector<double> wcat, bsum;
     for (int blk = 0; blk < 2; ++blk) {
         const int jb_ = 2 * blk;                               // lstms.0 / lstms.2: bidirectional over bands
         for (int layer = 0; layer < 2; ++layer) {
             const int IN = layer == 0 ? H : 2 * H, KT = IN + H, NS = KT / 4;
             std::vector<float> pk((size_t)2 * 4 * NS * 4 * 64), pb(2 * 256);
+            const int NB = KT / 32;
+            std::vector<uint16_t> pk16((size_t)2 * 4 * NB * 4 * 2 * 64 * 8);
             for (int d = 0; d < 2; ++d) {
                 lstm_cat(c, jb_, layer, d ? "_reverse" : "", IN, wcat, bsum);
+                for (int wv = 0; wv < 4; ++wv)
+                    for (int bk = 0; bk < NB; ++bk)
+                        for (int g = 0; g < 4; ++g)
+                            for (int ln = 0; ln < 64; ++ln)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int row = g * 64 + 16 * wv + (ln & 15);
+                                    const int k = 32 * bk + 8 * (ln >> 4) + e;
+                                    const float v = (float)wcat[(size_t)row * KT + k];
+                                    uint16_t pc[2];
+                                    split_planes_host(&v, 1, 2, pc);
+                                    const size_t base = ((((size_t)d * 4 + wv) * NB + bk) * 4 + g) * 2;
+                                    pk16[((base + 0) * 64 + ln) * 8 + e] = pc[0];
+                                    pk16[((base + 1) * 64 + ln) * 8 + e] = pc[1];
+                                }
                 for (int wv = 0; wv < 4; ++wv)
                     for (int s = 0; s < NS; ++s)
                         for (int g = 0; g < 4; ++g)
@@ -693,6 +710,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             }
             o_bandW[blk][layer] = ar.put(pk);
             o_bandB[blk][layer] = ar.put(pb);
+            o_bandW16[blk][layer] = ar.put(reinterpret_cast<const float*>(pk16.data()), pk16.size() / 2);
         }
         const int jt = 2 * blk + 1;                            // lstms.1 / lstms.3: causal over time
         std::vector<float> pk((size_t)2 * 4 * 128 * 64), pb(2 * 256);
@@ -728,6 +746,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         for (int layer = 0; layer < 2; ++layer) {
             c->bandW[blk][layer] = c->d_arena + o_bandW[blk][layer];
             c->bandB[blk][layer] = c->d_arena + o_bandB[blk][layer];
+            c->bandW16[blk][layer] = c->d_arena + o_bandW16[blk][layer];
         }
         c->timeW[blk] = c->d_arena + o_timeW[blk];
         c->timeB[blk] = c->d_arena + o_timeB[blk];
@@ -830,8 +849,8 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
     HIP_TRY(hipMemcpyAsync(c->Z0, z, nz * sizeof(float), hipMemcpyDeviceToDevice, s));
     const size_t slab = (size_t)2 * 2 * C * K * HID;
     for (int blk = 0; blk < 2; ++blk) {
-        launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandB[blk][0], M, K, 64, s);
-        launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandB[blk][1], M, K, 128, s);
+        launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, s);
+        launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, s);
         gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
         launch_time_lstm(c->Z1, c->H1, c->timeW[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
                          state_out ? state_out + blk * slab : nullptr, C, T, K, s);

@@ -63,8 +63,13 @@ constexpr int GEMM_BM = 128;
 //   xin  [N][L][IN]           IN = 64 (layer 0, fc_in folded into W_ih) or 128 (layer 1)
 //   hout [N][L][128]          forward half at [0,64), backward half at [64,128)
 //   wpk  packed [2 dir][4 wave][(IN+64)/4 step][4 gate][64 lane], bias [2][256]
-void launch_band_lstm(const float* xin, float* hout, const float* wpk, const float* bias,
+//   wpk16 (LSTM_FP16X2): the same matrix as two fp16 pieces in the f16 MFMA's B-operand order,
+//         [2 dir][4 wave][(IN+64)/32 blk][4 gate][2 piece][64 lane][8]
+void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       int N, int L, int IN, hipStream_t stream);
+// How the recurrent layers evaluate their gate products (environment BSRNN_LSTM = f32 | fp16x2, read once).
+enum LstmMode { LSTM_F32 = 0, LSTM_FP16X2 = 2 };
+int lstm_mode();
 // Time-axis LSTM, both layers pipelined in one launch, causal with state carry.
 //   zin/hout [R][T][K][64]; sequences n = r*K + k;  wpk packed [2 layer][4 wave][128 k][64 lane]
 //   state_in/out [2 (h,c)][2 layer][R*K][64] or null

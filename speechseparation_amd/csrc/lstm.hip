@@ -7,6 +7,10 @@
 // runs as one grouped-GEMM launch (gemm.hip, EPI_RES).
 #include "kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
 namespace bsrnn {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -146,15 +150,208 @@ __global__ __launch_bounds__(256, BAND_OCC) void band_lstm_kernel(const float* _
     }
 }
 
-void launch_band_lstm(const float* xin, float* hout, const float* wpk, const float* bias,
+// =====================================================================================
+// Band-axis BLSTM layer, split-precision variant (fp16x2, see gemm.hip): the gate pre-activations are computed
+// on the f16 matrix pipe, v_mfma_f32_16x16x32_f16, with both operands as two fp16 pieces (a ~ a1 + 2^-11 a2) and
+// three terms  hi += x1 w1,  lo += x1 w2 + x2 w1,  pre = bias + hi + 2^-11 lo  -  fp32-level accuracy at 3/16 of
+// the matrix-pipe time of the fp32 kernel above (which is bound by that pipe: 116 of 157 TFLOP/s).
+// Same decomposition: 16 sequences x 1 direction per workgroup, wave w owns units [16w, 16w+16) of all four gates,
+// so i,f,g,o of one cell share a lane; c and the fp32 arithmetic of the cell update are unchanged.
+//   * Weights: B operand, lane (n = l & 15, kb = l >> 4) holds W[gate row of unit 16w+n][32 blk + 8 kb .. +7] of
+//     each piece; packed on the host in exactly that order (one 16-byte load per lane and tile).  They stay in
+//     VGPRs, except the second piece of W_hh of the 128-input layer, which would not fit (192 + 32 accumulator
+//     registers) and is read from LDS every step (8 conflict-free ds_read_b128 per wave).
+//   * Activations: A operand, lane (m = l & 15, kb) holds x[m][32 blk + 8 kb .. +7]; x_t and h_t are kept in LDS
+//     as two fp16 planes in [k / 8][sequence][8] order, which makes every fragment read a linear,
+//     conflict-free ds_read_b128.  x is split by the staging threads, h by the lane that produced it.
+//   * The input half of step t+1 (x_{t+1} W_ih, independent of h_t) is issued after the cell update of step t,
+//     in front of the barrier that publishes h_t, so the matrix pipe works through the barrier skew.
+// =====================================================================================
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_h2(const float v, _Float16& p0, _Float16& p1)
+{
+    p0 = (_Float16)v;
+    p1 = (_Float16)((v - (float)p0) * 2048.f);
+}
+
+template <int IN>
+__global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __restrict__ xin, float* __restrict__ hout,
+                                                              const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                              int N, int L)
+{
+    constexpr int NBX = IN / 32, NBH = HID / 32, NB = NBX + NBH;
+    constexpr bool HLDS = IN == 128;             // second piece of W_hh lives in LDS
+    constexpr int XV = IN / 64;                  // float4 per thread per x tile
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[2][2][IN * 16];     // [slot][piece][k / 8][seq][8]
+    __shared__ __attribute__((aligned(16))) _Float16 hpl[2][2][HID * 16];
+    __shared__ __attribute__((aligned(16))) uint4 whh2[HLDS ? 4 * NBH * 4 * 64 : 1];
+
+    const int dir = blockIdx.y;
+    const int n0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+
+    // resident weights: w[blk][gate][piece]
+    h8v w[NB][4][2];
+    {
+        const uint4* wp = wpk + ((size_t)(dir * 4 + wave) * NB * 4 * 2) * 64 + lane;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    const uint4 v = wp[((b * 4 + gte) * 2 + pc) * 64];
+                    if (HLDS && b >= NBX && pc == 1)
+                        whh2[((wave * NBH + (b - NBX)) * 4 + gte) * 64 + lane] = v;
+                    else
+                        w[b][gte][pc] = __builtin_bit_cast(h8v, v);
+                }
+    }
+    float bs[4];
+#pragma unroll
+    for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[dir * 256 + gte * 64 + 16 * wave + l15];
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // x staging: XV float4 per thread: (row, 4 consecutive columns) -> 8 bytes of each piece
+    const int xr_row[2] = {(tid * XV) / (IN / 4), (tid * XV + 1) / (IN / 4)};
+    const int xr_c4[2] = {(tid * XV) % (IN / 4), (tid * XV + 1) % (IN / 4)};
+    auto xload = [&](int t, float4* dst) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            int row = n0 + xr_row[i];
+            row = row < N ? row : N - 1;
+            dst[i] = *reinterpret_cast<const float4*>(xin + ((size_t)row * L + t) * IN + 4 * xr_c4[i]);
+        }
+    };
+    auto xstore = [&](int slot, const float4* src) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const float v[4] = {src[i].x, src[i].y, src[i].z, src[i].w};
+            h4v p0, p1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float cl = __builtin_fminf(__builtin_fmaxf(v[e], -65504.f), 65504.f);
+                _Float16 a, b2;
+                split_h2(cl, a, b2);
+                p0[e] = a; p1[e] = b2;
+            }
+            const int o = ((xr_c4[i] >> 1) * 16 + xr_row[i]) * 8 + (xr_c4[i] & 1) * 4;
+            *reinterpret_cast<h4v*>(&xpl[slot][0][o]) = p0;
+            *reinterpret_cast<h4v*>(&xpl[slot][1][o]) = p1;
+        }
+    };
+    auto tmap = [&](int step) { return dir ? L - 1 - step : step; };
+
+    v4f hi[4], lo[4];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) { hi[gte] = (v4f){bs[gte], bs[gte], bs[gte], bs[gte]}; lo[gte] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+    };
+    const int frag = (q * 16 + l15) * 8;         // this lane's 16-byte unit inside a 32-deep block of a plane
+    auto x_part = [&](int slot) {
+#pragma unroll
+        for (int b = 0; b < NBX; ++b) {
+            const h8v a0 = *reinterpret_cast<const h8v*>(&xpl[slot][0][b * 512 + frag]);
+            const h8v a1 = *reinterpret_cast<const h8v*>(&xpl[slot][1][b * 512 + frag]);
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) {
+                hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[b][gte][0], hi[gte], 0, 0, 0);
+                lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[b][gte][1], lo[gte], 0, 0, 0);
+                lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[b][gte][0], lo[gte], 0, 0, 0);
+            }
+        }
+    };
+    auto h_part = [&](int slot) {
+#pragma unroll
+        for (int b = 0; b < NBH; ++b) {
+            const h8v a0 = *reinterpret_cast<const h8v*>(&hpl[slot][0][b * 512 + frag]);
+            const h8v a1 = *reinterpret_cast<const h8v*>(&hpl[slot][1][b * 512 + frag]);
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) {
+                const h8v w2 = HLDS ? __builtin_bit_cast(h8v, whh2[((wave * NBH + b) * 4 + gte) * 64 + lane]) : w[NBX + b][gte][1];
+                hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[NBX + b][gte][0], hi[gte], 0, 0, 0);
+                lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w2, lo[gte], 0, 0, 0);
+                lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[NBX + b][gte][0], lo[gte], 0, 0, 0);
+            }
+        }
+    };
+
+    {   // prologue: h_{-1} = 0 (slot 1), x of the first two steps, input half of step 0
+        *reinterpret_cast<uint4*>(&hpl[1][0][0] + tid * 8) = make_uint4(0, 0, 0, 0);      // 2 pieces x 1024 halves = 256 x 16 B
+        float4 x0[XV];
+        xload(tmap(0), x0);
+        xstore(0, x0);
+        if (L > 1) { xload(tmap(1), x0); xstore(1, x0); }
+    }
+    __syncthreads();
+    reset_acc();
+    x_part(0);
+
+    const int unit = 16 * wave + l15;
+    for (int step = 0; step < L; ++step) {
+        const int t = tmap(step);
+        float4 xn[XV];
+        const bool more2 = step + 2 < L;
+        if (more2) xload(tmap(step + 2), xn);
+
+        h_part((step + 1) & 1);                  // h_{step-1} lives in slot (step - 1) & 1
+
+        // cell update; C/D layout of the 16x16 MFMA: col (unit) = lane & 15, row (sequence) = 4*(lane>>4) + reg
+        _Float16* const hp0 = &hpl[step & 1][0][((unit >> 3) * 16) * 8 + (unit & 7)];
+        _Float16* const hp1 = &hpl[step & 1][1][((unit >> 3) * 16) * 8 + (unit & 7)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = fast_sigmoid(hi[0][r] + lo[0][r] * (1.f / 2048.f));
+            const float fg = fast_sigmoid(hi[1][r] + lo[1][r] * (1.f / 2048.f));
+            const float gg = fast_tanh(hi[2][r] + lo[2][r] * (1.f / 2048.f));
+            const float og = fast_sigmoid(hi[3][r] + lo[3][r] * (1.f / 2048.f));
+            c[r] = fg * c[r] + ig * gg;
+            const float hv = og * fast_tanh(c[r]);
+            const int m = 4 * q + r;
+            _Float16 p0, p1;
+            split_h2(hv, p0, p1);
+            hp0[m * 8] = p0;
+            hp1[m * 8] = p1;
+            if (n0 + m < N) hout[((size_t)(n0 + m) * L + t) * (2 * HID) + dir * HID + unit] = hv;
+        }
+        reset_acc();
+        if (step + 1 < L) x_part((step + 1) & 1);
+        if (more2) xstore(step & 1, xn);         // slot of x_step, whose readers finished before the last barrier
+        __syncthreads();
+    }
+}
+
+void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       int N, int L, int IN, hipStream_t stream)
 {
     if (N <= 0 || L <= 0) return;
     dim3 grid((N + 15) / 16, 2), block(256);
+    if (lstm_mode() == LSTM_FP16X2) {
+        if (IN == 64)
+            hipLaunchKernelGGL(band_lstm_h2_kernel<64>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L);
+        else
+            hipLaunchKernelGGL(band_lstm_h2_kernel<128>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L);
+        return;
+    }
     if (IN == 64)
         hipLaunchKernelGGL(band_lstm_kernel<64>, grid, block, 0, stream, xin, hout, wpk, bias, N, L);
     else
         hipLaunchKernelGGL(band_lstm_kernel<128>, grid, block, 0, stream, xin, hout, wpk, bias, N, L);
+}
+
+int lstm_mode()
+{
+    static const int mode = [] {
+        const char* e = getenv("BSRNN_LSTM");
+        if (!e || !*e || !strcmp(e, "fp16x2")) return (int)LSTM_FP16X2;
+        if (!strcmp(e, "f32")) return (int)LSTM_F32;
+        fprintf(stderr, "bsrnn: unknown BSRNN_LSTM='%s' (f32 | fp16x2), using fp16x2\n", e);
+        return (int)LSTM_FP16X2;
+    }();
+    return mode;
 }
 
 // =====================================================================================
