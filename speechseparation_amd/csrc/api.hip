@@ -75,7 +75,7 @@ struct bsrnn_ctx {
     int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT], tile_n[NSLOT];
 
     const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
-    const void* bandW16[2][2];                     // fp16x2 pieces in MFMA operand order (lstm.hip)
+    const void *bandW16[2][2], *timeW16[2];                     // fp16x2 pieces in MFMA operand order (lstm.hip)
     float* d_tables = nullptr;
     int* d_colmap = nullptr;
     FftTables tb;
@@ -368,7 +368,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     case MS_TIME0: case MS_TIME1: {   // TimewiseLSTM: N = C*K sequences of length T, causal, state carry   bsrnn.py:106-128
         const int blk = stage == MS_TIME1;
         StageScope sc(c, ST_TIME_LSTM, s);
-        launch_time_lstm(p.Z1, p.H1, c->timeW[blk], c->timeB[blk],
+        launch_time_lstm(p.Z1, p.H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
                          p.state_in ? p.state_in + blk * p.state_slab : nullptr,
                          p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, s);
         break;
@@ -673,7 +673,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     }
 
     // LSTM weights, folded and packed in the kernels' register order (lstm.hip)
-    size_t o_bandW[2][2], o_bandW16[2][2], o_bandB[2][2], o_timeW[2], o_timeB[2];
+    size_t o_bandW[2][2], o_bandW16[2][2], o_bandB[2][2], o_timeW[2], o_timeW16[2], o_timeB[2];
     std::vector<double> wcat, bsum;
     for (int blk = 0; blk < 2; ++blk) {
         const int jb_ = 2 * blk;                               // lstms.0 / lstms.2: bidirectional over bands
@@ -714,8 +714,23 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         }
         const int jt = 2 * blk + 1;                            // lstms.1 / lstms.3: causal over time
         std::vector<float> pk((size_t)2 * 4 * 128 * 64), pb(2 * 256);
+        std::vector<uint16_t> pk16((size_t)2 * 4 * 4 * 4 * 2 * 64 * 8);
         for (int layer = 0; layer < 2; ++layer) {
             lstm_cat(c, jt, layer, "", H, wcat, bsum);
+            for (int wv = 0; wv < 4; ++wv)
+                for (int bk = 0; bk < 4; ++bk)
+                    for (int g = 0; g < 4; ++g)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int e = 0; e < 8; ++e) {
+                                const int row = g * 64 + 16 * wv + (ln & 15);
+                                const int k = 32 * bk + 8 * (ln >> 4) + e;
+                                const float v = (float)wcat[(size_t)row * 128 + k];
+                                uint16_t pc[2];
+                                split_planes_host(&v, 1, 2, pc);
+                                const size_t base = ((((size_t)layer * 4 + wv) * 4 + bk) * 4 + g) * 2;
+                                pk16[((base + 0) * 64 + ln) * 8 + e] = pc[0];
+                                pk16[((base + 1) * 64 + ln) * 8 + e] = pc[1];
+                            }
             for (int wv = 0; wv < 4; ++wv)
                 for (int k = 0; k < 128; ++k)
                     for (int ln = 0; ln < 64; ++ln) {
@@ -725,6 +740,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             for (int r = 0; r < 256; ++r) pb[layer * 256 + r] = (float)bsum[r];
         }
         o_timeW[blk] = ar.put(pk);
+        o_timeW16[blk] = ar.put(reinterpret_cast<const float*>(pk16.data()), pk16.size() / 2);
         o_timeB[blk] = ar.put(pb);
     }
 
@@ -749,6 +765,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             c->bandW16[blk][layer] = c->d_arena + o_bandW16[blk][layer];
         }
         c->timeW[blk] = c->d_arena + o_timeW[blk];
+        c->timeW16[blk] = c->d_arena + o_timeW16[blk];
         c->timeB[blk] = c->d_arena + o_timeB[blk];
     }
     c->committed = true;
@@ -852,7 +869,7 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
         launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, s);
         launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, s);
         gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
-        launch_time_lstm(c->Z1, c->H1, c->timeW[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
+        launch_time_lstm(c->Z1, c->H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
                          state_out ? state_out + blk * slab : nullptr, C, T, K, s);
         gemm_slot(c, BLK_FC1 + 2 * blk, c->H1, HID, c->Z0, HID, c->Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
     }

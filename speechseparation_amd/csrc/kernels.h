@@ -73,7 +73,8 @@ int lstm_mode();
 // Time-axis LSTM, both layers pipelined in one launch, causal with state carry.
 //   zin/hout [R][T][K][64]; sequences n = r*K + k;  wpk packed [2 layer][4 wave][128 k][64 lane]
 //   state_in/out [2 (h,c)][2 layer][R*K][64] or null
-void launch_time_lstm(const float* zin, float* hout, const float* wpk, const float* bias,
+//   wpk16 (LSTM_FP16X2): two fp16 pieces in B-operand order, [2 layer][4 wave][4 blk][4 gate][2 piece][64 lane][8]
+void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, hipStream_t stream);
 
 // ------------------------------------------------------------------ STFT / iSTFT / layout

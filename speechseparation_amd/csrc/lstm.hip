@@ -510,12 +510,178 @@ __global__ __launch_bounds__(512) void time_lstm_kernel(const float* __restrict_
     }
 }
 
-void launch_time_lstm(const float* zin, float* hout, const float* wpk, const float* bias,
+// =====================================================================================
+// Time-axis LSTM, split-precision variant (fp16x2 on v_mfma_f32_16x16x32_f16, as the band kernel above).
+// The fp32 kernel's step is bound by the 4x4x1 MFMA stream (2 waves x 128 MFMAs x 9.5 cycles per SIMD and
+// step); here a wave needs 48 MFMAs of 16 cycles.  Same decomposition (4 sequences per workgroup, waves 0-3
+// layer 0, waves 4-7 layer 1 one step behind, one barrier per step), different operand roles:
+//   A = activations, 16 rows of which row 4j carries sequence j (the other rows repeat it and are ignored),
+//   B = weights, tile g = gate g of the wave's 16 units (column n = unit 16w+n), resident in VGPRs,
+// so accumulator register 0 of lane (n, q = lane >> 4) is gate g of cell (unit 16w+n, sequence q): every lane
+// owns exactly one cell and its four gates, no cross-lane traffic.  x_t / h_t live in LDS as two fp16 planes in
+// [k / 8][sequence][8] order (fragment reads are conflict-free ds_read_b128, replicas read the same address).
+// Phase order per step, chosen so that the two waves of a SIMD keep its matrix pipe busy in turns:
+//   layer 0:  recurrent half (h0_{s-1})            -> cell(s)   -> input half of step s+1 (x_{s+1})
+//   layer 1:  input half (h0_{s-1}) + recurrent half (h1_{s-2}) -> cell(s-1)
+// =====================================================================================
+__global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restrict__ zin, float* __restrict__ hout,
+                                                           const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                           const float* __restrict__ state_in, float* __restrict__ state_out,
+                                                           int R, int T, int K)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[2][TCH][2][4 * HID];     // [chunk slot][step][piece][k/8][seq][8]
+    __shared__ __attribute__((aligned(16))) _Float16 h0pl[2][2][4 * HID];
+    __shared__ __attribute__((aligned(16))) _Float16 h1pl[2][2][4 * HID];
+
+    const int N = R * K;
+    const int n0 = blockIdx.x * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int layer = wave >> 2, w4 = wave & 3;
+    const int n = lane & 15, q = lane >> 4;
+    const int unit = 16 * w4 + n;
+    const size_t tstride = (size_t)K * HID;
+
+    // this lane's cell: (unit, sequence q)
+    const int nq_raw = n0 + q;
+    const int nq = nq_raw < N ? nq_raw : N - 1;
+    const size_t base_q = ((size_t)(nq / K) * T * K + (nq % K)) * HID;
+
+    h8v w[4][4][2];                               // [k block: 0,1 input half, 2,3 recurrent half][gate][piece]
+    {
+        const uint4* wp = wpk + ((size_t)(layer * 4 + w4) * 4 * 4 * 2) * 64 + lane;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[((b * 4 + gte) * 2 + pc) * 64]);
+    }
+    float bs[4];
+#pragma unroll
+    for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[layer * 256 + gte * 64 + unit];
+
+    const int hoff = ((unit >> 3) * 4 + q) * 8 + (unit & 7);      // where this lane's h goes inside a plane
+    float c = state_in ? state_in[((size_t)(2 + layer) * N + nq) * HID + unit] : 0.f;
+    {
+        const float hinit = state_in ? state_in[((size_t)layer * N + nq) * HID + unit] : 0.f;
+        _Float16 p0, p1;
+        split_h2(hinit, p0, p1);
+        _Float16(*hb)[4 * HID] = layer ? h1pl[1] : h0pl[1];        // h_{-1} lives in slot 1
+        hb[0][hoff] = p0;
+        hb[1][hoff] = p1;
+    }
+
+    // x chunk staging: 8 steps x 4 sequences x 16 float4 = 512 float4, one per thread, split on the way into LDS
+    const int xs_t = tid >> 6, xs_i = (tid >> 4) & 3, xs_c4 = tid & 15;
+    size_t xs_base;
+    {
+        int ni = n0 + xs_i; ni = ni < N ? ni : N - 1;
+        xs_base = ((size_t)(ni / K) * T * K + (ni % K)) * HID + 4 * xs_c4;
+    }
+    auto chunk_load = [&](int chunk) -> float4 {
+        int t = chunk * TCH + xs_t;
+        t = t < T ? t : T - 1;
+        return *reinterpret_cast<const float4*>(zin + xs_base + (size_t)t * tstride);
+    };
+    auto chunk_store = [&](int chunk, float4 v) {
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        h4v p0, p1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 a, b2;
+            split_h2(__builtin_fminf(__builtin_fmaxf(f[e], -65504.f), 65504.f), a, b2);
+            p0[e] = a; p1[e] = b2;
+        }
+        const int o = ((xs_c4 >> 1) * 4 + xs_i) * 8 + (xs_c4 & 1) * 4;
+        *reinterpret_cast<h4v*>(&xpl[chunk & 1][xs_t][0][o]) = p0;
+        *reinterpret_cast<h4v*>(&xpl[chunk & 1][xs_t][1][o]) = p1;
+    };
+    chunk_store(0, chunk_load(0));
+    float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    float hsel = 0.f, csel = 0.f;
+    __syncthreads();
+
+    v4f hi[4], lo[4];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) { hi[gte] = (v4f){bs[gte], bs[gte], bs[gte], bs[gte]}; lo[gte] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+    };
+    // A fragment of this lane inside a 32-deep block of a plane: row l & 15 carries sequence (l & 15) >> 2
+    const int afrag = (q * 4 + (n >> 2)) * 8;
+    auto half_gemv = [&](const _Float16 (*src)[4 * HID], const int wofs) {
+        h8v a0[2], a1[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            a0[b] = *reinterpret_cast<const h8v*>(&src[0][b * 128 + afrag]);
+            a1[b] = *reinterpret_cast<const h8v*>(&src[1][b * 128 + afrag]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[wofs + b][gte][0], hi[gte], 0, 0, 0);
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[wofs + b][gte][1], lo[gte], 0, 0, 0);
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[b], w[wofs + b][gte][0], lo[gte], 0, 0, 0);
+        }
+    };
+    auto cell = [&](int t) {
+        const float ig = fast_sigmoid(hi[0][0] + lo[0][0] * (1.f / 2048.f));
+        const float fg = fast_sigmoid(hi[1][0] + lo[1][0] * (1.f / 2048.f));
+        const float gg = fast_tanh(hi[2][0] + lo[2][0] * (1.f / 2048.f));
+        const float og = fast_sigmoid(hi[3][0] + lo[3][0] * (1.f / 2048.f));
+        c = fg * c + ig * gg;
+        hsel = og * fast_tanh(c);
+        csel = c;
+        _Float16 p0, p1;
+        split_h2(hsel, p0, p1);
+        _Float16(*hb)[4 * HID] = layer ? h1pl[t & 1] : h0pl[t & 1];
+        hb[0][hoff] = p0;
+        hb[1][hoff] = p1;
+        if (layer && nq_raw < N) hout[base_q + (size_t)t * tstride + unit] = hsel;
+    };
+
+    if (layer == 0) { reset_acc(); half_gemv(xpl[0][0], 0); }       // input half of step 0
+    for (int s = 0; s <= T; ++s) {
+        const int chunk = s / TCH, sin = s % TCH;
+        const bool have_next = (chunk + 1) * TCH < T;
+        if (sin == 0 && have_next) xnext = chunk_load(chunk + 1);
+
+        if (layer == 0) {
+            if (s < T) {
+                half_gemv(h0pl[(s + 1) & 1], 2);                    // recurrent half, h0_{s-1}
+                cell(s);
+                reset_acc();
+                if (s + 1 < T) half_gemv(xpl[((s + 1) / TCH) & 1][(s + 1) % TCH], 0);   // input half of step s+1
+            }
+        } else if (s >= 1) {
+            const int t = s - 1;
+            reset_acc();
+            half_gemv(h0pl[t & 1], 0);                              // input half, h0_t
+            half_gemv(h1pl[(t + 1) & 1], 2);                        // recurrent half, h1_{t-1}
+            cell(t);
+        }
+        // x of the next chunk is first read in the iteration before its first step (layer 0's look-ahead)
+        if (sin == TCH - 2 && have_next) chunk_store(chunk + 1, xnext);
+        __syncthreads();
+    }
+
+    if (state_out && nq_raw < N) {
+        state_out[((size_t)layer * N + nq) * HID + unit] = hsel;           // h_{T-1}
+        state_out[((size_t)(2 + layer) * N + nq) * HID + unit] = csel;     // c_{T-1}
+    }
+}
+
+void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, hipStream_t stream)
 {
     const int N = R * K;
     if (N <= 0 || T <= 0) return;
     dim3 grid((N + 3) / 4), block(512);
+    if (lstm_mode() == LSTM_FP16X2) {
+        hipLaunchKernelGGL(time_lstm_h2_kernel, grid, block, 0, stream, zin, hout, (const uint4*)wpk16, bias, state_in, state_out, R, T, K);
+        return;
+    }
     hipLaunchKernelGGL(time_lstm_kernel, grid, block, 0, stream, zin, hout, wpk, bias, state_in, state_out, R, T, K,
                        (unsigned long long*)nullptr);
 }
