@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256, BAND_OCC) void band_lstm_kernel(const float* _
 // so i,f,g,o of one cell share a lane; c and the fp32 arithmetic of the cell update are unchanged.
 //   * Weights: B operand, lane (n = l & 15, kb = l >> 4) holds W[gate row of unit 16w+n][32 blk + 8 kb .. +7] of
 //     each piece; packed on the host in exactly that order (one 16-byte load per lane and tile).  They stay in
-//     VGPRs, except the second piece of W_hh of the 128-input layer, which would not fit (192 + 32 accumulator
-//     registers) and is read from LDS every step (8 conflict-free ds_read_b128 per wave).
+//     VGPRs, except three of the six second-piece blocks of the 128-input layer, which would not fit (192 + 32
+//     accumulator registers) and are read from LDS every step (12 conflict-free ds_read_b128 per wave).
 //   * Activations: A operand, lane (m = l & 15, kb) holds x[m][32 blk + 8 kb .. +7]; x_t and h_t are kept in LDS
 //     as two fp16 planes in [k / 8][sequence][8] order, which makes every fragment read a linear,
 //     conflict-free ds_read_b128.  x is split by the staging threads, h by the lane that produced it.
@@ -176,17 +176,24 @@ __device__ __forceinline__ void split_h2(const float v, _Float16& p0, _Float16& 
     p1 = (_Float16)((v - (float)p0) * 2048.f);
 }
 
-template <int IN>
+template <int IN, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __restrict__ xin, float* __restrict__ hout,
                                                               const uint4* __restrict__ wpk, const float* __restrict__ bias,
-                                                              int N, int L)
+                                                              int N, int L, unsigned long long* __restrict__ dbg)
 {
+    // measurement only (TRACE, tools/lstm_h2_trace.hip): 100 MHz stamps per phase, accumulated per wave
+    unsigned long long tp[5] = {0, 0, 0, 0, 0}, tq = 0;
+    auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
+    if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
     constexpr int NBX = IN / 32, NBH = HID / 32, NB = NBX + NBH;
-    constexpr bool HLDS = IN == 128;             // second piece of W_hh lives in LDS
+    // blocks whose second weight piece lives in LDS instead of VGPRs (counted from the last k block): the 128-input
+    // layer would need 192 weight + 32 accumulator registers; with 3 blocks (both of W_hh, the last of W_ih) in LDS
+    // it is 144 + 32 and compiles without scratch (measured with spills: 1.9 us of every 3.5 us step in reloads)
+    constexpr int NLDS = IN == 128 ? 3 : 0;
     constexpr int XV = IN / 64;                  // float4 per thread per x tile
     __shared__ __attribute__((aligned(16))) _Float16 xpl[2][2][IN * 16];     // [slot][piece][k / 8][seq][8]
     __shared__ __attribute__((aligned(16))) _Float16 hpl[2][2][HID * 16];
-    __shared__ __attribute__((aligned(16))) uint4 whh2[HLDS ? 4 * NBH * 4 * 64 : 1];
+    __shared__ __attribute__((aligned(16))) uint4 w2lds[NLDS ? 4 * NLDS * 4 * 64 : 1];
 
     const int dir = blockIdx.y;
     const int n0 = blockIdx.x * 16;
@@ -204,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc) {
                     const uint4 v = wp[((b * 4 + gte) * 2 + pc) * 64];
-                    if (HLDS && b >= NBX && pc == 1)
-                        whh2[((wave * NBH + (b - NBX)) * 4 + gte) * 64 + lane] = v;
+                    if (pc == 1 && b >= NB - NLDS)
+                        w2lds[((wave * NLDS + (b - (NB - NLDS))) * 4 + gte) * 64 + lane] = v;
                     else
                         w[b][gte][pc] = __builtin_bit_cast(h8v, v);
                 }
@@ -251,31 +258,48 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         for (int gte = 0; gte < 4; ++gte) { hi[gte] = (v4f){bs[gte], bs[gte], bs[gte], bs[gte]}; lo[gte] = (v4f){0.f, 0.f, 0.f, 0.f}; }
     };
     const int frag = (q * 16 + l15) * 8;         // this lane's 16-byte unit inside a 32-deep block of a plane
+    auto block_mfma = [&](const int b, const h8v a0, const h8v a1) {
+        h8v w2[4];
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte)
+            w2[gte] = b >= NB - NLDS ? __builtin_bit_cast(h8v, w2lds[((wave * NLDS + (b - (NB - NLDS))) * 4 + gte) * 64 + lane]) : w[b][gte][1];
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[b][gte][0], hi[gte], 0, 0, 0);
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[b][gte][0], lo[gte], 0, 0, 0);
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w2[gte], lo[gte], 0, 0, 0);
+    };
+    // fragments one block ahead of the MFMAs; the scheduling fences keep the compiler from hoisting every block's
+    // ds_reads to the top (register pressure: the 128-input layer sits at the 256-VGPR limit of 2 waves per SIMD)
     auto x_part = [&](int slot) {
+        h8v a0 = *reinterpret_cast<const h8v*>(&xpl[slot][0][frag]);
+        h8v a1 = *reinterpret_cast<const h8v*>(&xpl[slot][1][frag]);
 #pragma unroll
         for (int b = 0; b < NBX; ++b) {
-            const h8v a0 = *reinterpret_cast<const h8v*>(&xpl[slot][0][b * 512 + frag]);
-            const h8v a1 = *reinterpret_cast<const h8v*>(&xpl[slot][1][b * 512 + frag]);
-#pragma unroll
-            for (int gte = 0; gte < 4; ++gte) {
-                hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[b][gte][0], hi[gte], 0, 0, 0);
-                lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[b][gte][1], lo[gte], 0, 0, 0);
-                lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[b][gte][0], lo[gte], 0, 0, 0);
+            h8v n0v = a0, n1v = a1;
+            if (b + 1 < NBX) {
+                n0v = *reinterpret_cast<const h8v*>(&xpl[slot][0][(b + 1) * 512 + frag]);
+                n1v = *reinterpret_cast<const h8v*>(&xpl[slot][1][(b + 1) * 512 + frag]);
             }
+            block_mfma(b, a0, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0v; a1 = n1v;
         }
     };
     auto h_part = [&](int slot) {
+        h8v a0 = *reinterpret_cast<const h8v*>(&hpl[slot][0][frag]);
+        h8v a1 = *reinterpret_cast<const h8v*>(&hpl[slot][1][frag]);
 #pragma unroll
         for (int b = 0; b < NBH; ++b) {
-            const h8v a0 = *reinterpret_cast<const h8v*>(&hpl[slot][0][b * 512 + frag]);
-            const h8v a1 = *reinterpret_cast<const h8v*>(&hpl[slot][1][b * 512 + frag]);
-#pragma unroll
-            for (int gte = 0; gte < 4; ++gte) {
-                const h8v w2 = HLDS ? __builtin_bit_cast(h8v, whh2[((wave * NBH + b) * 4 + gte) * 64 + lane]) : w[NBX + b][gte][1];
-                hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[NBX + b][gte][0], hi[gte], 0, 0, 0);
-                lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w2, lo[gte], 0, 0, 0);
-                lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[NBX + b][gte][0], lo[gte], 0, 0, 0);
+            h8v n0v = a0, n1v = a1;
+            if (b + 1 < NBH) {
+                n0v = *reinterpret_cast<const h8v*>(&hpl[slot][0][(b + 1) * 512 + frag]);
+                n1v = *reinterpret_cast<const h8v*>(&hpl[slot][1][(b + 1) * 512 + frag]);
             }
+            block_mfma(NBX + b, a0, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0v; a1 = n1v;
         }
     };
 
@@ -289,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     __syncthreads();
     reset_acc();
     x_part(0);
+    stamp(0);
 
     const int unit = 16 * wave + l15;
     for (int step = 0; step < L; ++step) {
@@ -298,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         if (more2) xload(tmap(step + 2), xn);
 
         h_part((step + 1) & 1);                  // h_{step-1} lives in slot (step - 1) & 1
+        stamp(1);
 
         // cell update; C/D layout of the 16x16 MFMA: col (unit) = lane & 15, row (sequence) = 4*(lane>>4) + reg
         _Float16* const hp0 = &hpl[step & 1][0][((unit >> 3) * 16) * 8 + (unit & 7)];
@@ -317,10 +343,18 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
             hp1[m * 8] = p1;
             if (n0 + m < N) hout[((size_t)(n0 + m) * L + t) * (2 * HID) + dir * HID + unit] = hv;
         }
+        stamp(2);
         reset_acc();
         if (step + 1 < L) x_part((step + 1) & 1);
         if (more2) xstore(step & 1, xn);         // slot of x_step, whose readers finished before the last barrier
+        stamp(3);
         __syncthreads();
+        stamp(4);
+    }
+    if (TRACE && lane == 0 && blockIdx.x < 4 && blockIdx.y == 0) {
+        unsigned long long* d = dbg + (blockIdx.x * 4 + wave) * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d[k] = tp[k];
     }
 }
 
@@ -331,9 +365,9 @@ void launch_band_lstm(const float* xin, float* hout, const float* wpk, const voi
     dim3 grid((N + 15) / 16, 2), block(256);
     if (lstm_mode() == LSTM_FP16X2) {
         if (IN == 64)
-            hipLaunchKernelGGL(band_lstm_h2_kernel<64>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L);
+            hipLaunchKernelGGL(band_lstm_h2_kernel<64>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, (unsigned long long*)nullptr);
         else
-            hipLaunchKernelGGL(band_lstm_h2_kernel<128>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L);
+            hipLaunchKernelGGL(band_lstm_h2_kernel<128>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, (unsigned long long*)nullptr);
         return;
     }
     if (IN == 64)
@@ -524,11 +558,14 @@ __global__ __launch_bounds__(512) void time_lstm_kernel(const float* __restrict_
 //   layer 0:  recurrent half (h0_{s-1})            -> cell(s)   -> input half of step s+1 (x_{s+1})
 //   layer 1:  input half (h0_{s-1}) + recurrent half (h1_{s-2}) -> cell(s-1)
 // =====================================================================================
+template <bool TRACE = false>
 __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restrict__ zin, float* __restrict__ hout,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
                                                            const float* __restrict__ state_in, float* __restrict__ state_out,
-                                                           int R, int T, int K)
+                                                           int R, int T, int K, unsigned long long* __restrict__ dbg)
 {
+    unsigned long long tp[5] = {0, 0, 0, 0, 0}, tq = 0;       // measurement only, as in the band kernel
+    auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
     __shared__ __attribute__((aligned(16))) _Float16 xpl[2][TCH][2][4 * HID];     // [chunk slot][step][piece][k/8][seq][8]
     __shared__ __attribute__((aligned(16))) _Float16 h0pl[2][2][4 * HID];
     __shared__ __attribute__((aligned(16))) _Float16 h1pl[2][2][4 * HID];
@@ -642,28 +679,42 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
     };
 
     if (layer == 0) { reset_acc(); half_gemv(xpl[0][0], 0); }       // input half of step 0
+    if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
     for (int s = 0; s <= T; ++s) {
         const int chunk = s / TCH, sin = s % TCH;
         const bool have_next = (chunk + 1) * TCH < T;
         if (sin == 0 && have_next) xnext = chunk_load(chunk + 1);
+        stamp(4);
 
         if (layer == 0) {
             if (s < T) {
                 half_gemv(h0pl[(s + 1) & 1], 2);                    // recurrent half, h0_{s-1}
+                stamp(1);
                 cell(s);
+                stamp(2);
                 reset_acc();
                 if (s + 1 < T) half_gemv(xpl[((s + 1) / TCH) & 1][(s + 1) % TCH], 0);   // input half of step s+1
+                stamp(0);
             }
         } else if (s >= 1) {
             const int t = s - 1;
             reset_acc();
             half_gemv(h0pl[t & 1], 0);                              // input half, h0_t
+            stamp(0);
             half_gemv(h1pl[(t + 1) & 1], 2);                        // recurrent half, h1_{t-1}
+            stamp(1);
             cell(t);
+            stamp(2);
         }
         // x of the next chunk is first read in the iteration before its first step (layer 0's look-ahead)
         if (sin == TCH - 2 && have_next) chunk_store(chunk + 1, xnext);
         __syncthreads();
+        stamp(3);
+    }
+    if (TRACE && lane == 0 && blockIdx.x < 4) {
+        unsigned long long* d = dbg + (blockIdx.x * 8 + wave) * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d[k] = tp[k];
     }
 
     if (state_out && nq_raw < N) {
@@ -679,7 +730,8 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const voi
     if (N <= 0 || T <= 0) return;
     dim3 grid((N + 3) / 4), block(512);
     if (lstm_mode() == LSTM_FP16X2) {
-        hipLaunchKernelGGL(time_lstm_h2_kernel, grid, block, 0, stream, zin, hout, (const uint4*)wpk16, bias, state_in, state_out, R, T, K);
+        hipLaunchKernelGGL(time_lstm_h2_kernel<false>, grid, block, 0, stream, zin, hout, (const uint4*)wpk16, bias, state_in, state_out, R, T, K,
+                           (unsigned long long*)nullptr);
         return;
     }
     hipLaunchKernelGGL(time_lstm_kernel, grid, block, 0, stream, zin, hout, wpk, bias, state_in, state_out, R, T, K,

@@ -1,0 +1,89 @@
+// Measurement-only: phase breakdown of the fp16x2 band / time LSTM kernels (100 MHz stamps inside the kernels).
+//   hipcc -O3 --offload-arch=gfx950 -o build/lstm_h2_trace tools/lstm_h2_trace.hip
+#include "../speechseparation_amd/csrc/lstm.hip"
+#include <cstdio>
+#include <vector>
+using namespace bsrnn;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int IN>
+static int run_band(int N, int L)
+{
+    const size_t nx = (size_t)N * L * IN, nh = (size_t)N * L * 128;
+    constexpr int NB = (IN + 64) / 32;
+    const size_t nw = (size_t)2 * 4 * NB * 4 * 2 * 64 * 8;          // halves
+    float *x, *h, *b; uint16_t* w; unsigned long long* dbg;
+    CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&h, nh * 4)); CK(hipMalloc(&w, nw * 2)); CK(hipMalloc(&b, 512 * 4));
+    CK(hipMalloc(&dbg, 4 * 4 * 5 * 8));
+    std::vector<float> hx(nx);
+    for (auto& v : hx) v = (rand() / (float)RAND_MAX - 0.5f);
+    std::vector<uint16_t> hw(nw);
+    for (auto& v : hw) v = (uint16_t)(0x2c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));   // fp16 in +-[0.06, 0.12)
+    CK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(b, 0, 512 * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        if (rep == 3) hipLaunchKernelGGL((band_lstm_h2_kernel<IN, true>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, dbg);
+        else hipLaunchKernelGGL((band_lstm_h2_kernel<IN, false>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, dbg);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("band_lstm_h2<%d> N=%d L=%d launch %d: %.1f us\n", IN, N, L, rep, ms * 1e3);
+    }
+    unsigned long long hd[4 * 4 * 5];
+    CK(hipMemcpy(hd, dbg, sizeof hd, hipMemcpyDeviceToHost));
+    const char* nm[5] = {"prologue", "h part", "cell+publish", "x part+xstore", "barrier"};
+    for (int blk = 0; blk < 2; ++blk)
+        for (int wv = 0; wv < 4; wv += 3) {
+            printf("  block %d wave %d:", blk, wv);
+            double tot = 0;
+            for (int k = 0; k < 5; ++k) tot += hd[(blk * 4 + wv) * 5 + k];
+            for (int k = 0; k < 5; ++k) printf("  %s %.2f us", nm[k], hd[(blk * 4 + wv) * 5 + k] / 100.0);
+            printf("  total %.1f us (%.0f ns/step w/o prologue)\n", tot / 100.0, (tot - hd[(blk * 4 + wv) * 5]) * 10.0 / L);
+        }
+    return 0;
+}
+
+static int run_time(int R, int T, int K)
+{
+    const size_t nz = (size_t)R * T * K * 64;
+    const size_t nw = (size_t)2 * 4 * 4 * 4 * 2 * 64 * 8;
+    float *z, *h, *b; uint16_t* w; unsigned long long* dbg;
+    CK(hipMalloc(&z, nz * 4)); CK(hipMalloc(&h, nz * 4)); CK(hipMalloc(&w, nw * 2)); CK(hipMalloc(&b, 512 * 4));
+    CK(hipMalloc(&dbg, 4 * 8 * 5 * 8));
+    std::vector<float> hz(nz);
+    for (auto& v : hz) v = (rand() / (float)RAND_MAX - 0.5f);
+    std::vector<uint16_t> hw(nw);
+    for (auto& v : hw) v = (uint16_t)(0x2c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
+    CK(hipMemcpy(z, hz.data(), nz * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(b, 0, 512 * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        if (rep == 3) hipLaunchKernelGGL(time_lstm_h2_kernel<true>, dim3(R * K / 4), dim3(512), 0, 0, z, h, (const uint4*)w, b, (const float*)nullptr, (float*)nullptr, R, T, K, dbg);
+        else hipLaunchKernelGGL(time_lstm_h2_kernel<false>, dim3(R * K / 4), dim3(512), 0, 0, z, h, (const uint4*)w, b, (const float*)nullptr, (float*)nullptr, R, T, K, dbg);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("time_lstm_h2 launch %d: %.1f us\n", rep, ms * 1e3);
+    }
+    unsigned long long hd[4 * 8 * 5];
+    CK(hipMemcpy(hd, dbg, sizeof hd, hipMemcpyDeviceToHost));
+    const char* nm[5] = {"input half", "recurrent half", "cell+publish", "barrier", "loop/chunk"};
+    for (int blk = 0; blk < 2; ++blk)
+        for (int wv = 0; wv < 8; wv += 4) {
+            printf("  block %d wave %d (layer %d):", blk, wv, wv / 4);
+            double tot = 0;
+            for (int k = 0; k < 5; ++k) tot += hd[(blk * 8 + wv) * 5 + k];
+            for (int k = 0; k < 5; ++k) printf("  %s %.0f ns/step", nm[k], hd[(blk * 8 + wv) * 5 + k] * 10.0 / T);
+            printf("  total %.1f us\n", tot / 100.0);
+        }
+    return 0;
+}
+
+int main()
+{
+    if (run_band<64>(8064, 12)) return 1;
+    if (run_band<128>(8064, 12)) return 1;
+    if (run_band<128>(256, 12)) return 1;       // a single round of workgroups, 1 per CU
+    return run_time(64, 126, 12);
+}
