@@ -73,7 +73,25 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("BSRNN_CPU_THREADS", "16"))))
 
 
-def profiled_traffic():
+# The ten grouped-GEMM launches of the two bracketed stages, by kernel instance (template arguments as rocprofv3
+# prints them) -> launches per step.  Split kernels: <epilogue, pieces, tile (1 = 128x64, 2 = 128x128), ...>.
+GEMM_LAUNCH_MIX = {
+    "f32": (("gemm_f32_kernel<1,", 8), ("gemm_f32_kernel<0,", 1), ("gemm_f32_kernel<3,", 1)),
+    "fp16x2": (("gemm_split_kernel<1, 2, 2,", 6), ("gemm_split_kernel<1, 2, 1,", 2), ("gemm_split_kernel<0, 2, 1,", 1),
+               ("gemm_split_kernel<3, 2, 2,", 1)),
+    "bf16x3": (("gemm_split_kernel<1, 3, 2,", 6), ("gemm_split_kernel<1, 3, 1,", 2), ("gemm_split_kernel<0, 3, 1,", 1),
+               ("gemm_split_kernel<3, 3, 2,", 1)),
+}
+# matrix-pipe roofline of the grouped GEMM per mode: (kernel, peak in algorithmic TFLOP/s, how it is derived)
+GEMM_ROOF = {
+    "f32": ("gemm_f32_kernel", 157.3, "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32, exact fp32)"),
+    "fp16x2": ("gemm_split_kernel<fp16x2>", 2500.0 / 3, "f16 MFMA dense peak 2500 TFLOP/s / 3 MFMA terms per fp32-accurate product "
+               "(a1b1 + a1b2 + a2b1, fp32 accumulate)"),
+    "bf16x3": ("gemm_split_kernel<bf16x3>", 2500.0 / 6, "bf16 MFMA dense peak 2500 TFLOP/s / 6 MFMA terms per fp32-accurate product"),
+}
+
+
+def profiled_traffic(gemm):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/rNN_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE and
     WRITE_SIZE passes with the gfx950 x2 fetch correction).  The bracketed stages launch the LEAKY
@@ -84,7 +102,7 @@ def profiled_traffic():
         return None, None
     d = json.load(open(files[-1]))
     tot = 0.0
-    for key, n in (("gemm_f32_kernel<1,", 8), ("gemm_f32_kernel<0,", 1), ("gemm_f32_kernel<3,", 1)):
+    for key, n in GEMM_LAUNCH_MIX[gemm]:
         hit = [v for k, v in d.items() if k.startswith(key)]
         if not hit:
             return None, None
@@ -202,14 +220,18 @@ def main():
         dom_ms_step = sum(dom_stages[k][0] for k in DOMINANT) / args.steps
         dom_flop_step = 2 * sum(macs[k] for k in DOMINANT) * rf
         n_launch = 10
-        traffic, traffic_src = profiled_traffic()
+        from speechseparation_amd import _native
+        cmode = _native.compute_mode()
+        kname, peak, basis = GEMM_ROOF[cmode["gemm"]]
+        traffic, traffic_src = profiled_traffic(cmode["gemm"])
         achieved = dom_flop_step / (dom_ms_step * 1e-3) / 1e12
-        roofline = {"kernel": "gemm_f32_kernel (grouped per-band Linear layers: bandsplit_mlp + mask_mlp, %d launches/step)" % n_launch,
-                    "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        roofline = {"kernel": "%s (grouped per-band Linear layers: bandsplit_mlp + mask_mlp, %d launches/step)" % (kname, n_launch),
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms_step / n_launch, 4), "launches_per_step": n_launch,
-                    "flop_per_launch_avg": dom_flop_step / n_launch,
-                    "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); flops = 2 x MACs of the Linear layers x row-frames; "
+                    "flop_per_launch_avg": dom_flop_step / n_launch, "peak_basis": basis,
+                    "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "note": "achieved = algorithmic flops (2 x MACs of the Linear layers x row-frames, fp32 semantics) / launch time; "
                             "HIP events on the launch stream over the timed region"}
         dp_ms = sum(per_step.get(k, 0.0) for k in ("band_lstm", "band_fc", "time_lstm", "time_fc"))
         dp_gbs = BYTES_DUAL_PATH * rf / (dp_ms * 1e-3) / 1e9 if dp_ms else 0.0
@@ -227,6 +249,8 @@ def main():
                        "rows_per_gpu": args.rows, "global_rows": args.rows * world, "frames": T, "parallelism": "dp%d (row shards, no in-path collective)" % world},
             "rtf": round(elapsed / args.steps / (args.rows * args.samples / 16000.0), 8),
             "pipeline_hbm": {"achieved_GBs": round(BYTES_PIPELINE * rf / (ms_per_step * 1e-3) / 1e9, 1), "peak_GBs": PEAK_HBM_GBS},
+            "compute": dict(cmode, note="fp32 in/out/state/accumulate; products of fp32 operands split into 16-bit pieces on the "
+                                        "f16/bf16 matrix cores unless 'f32' (error at fp32 rounding level, DESIGN.md)"),
             "roofline": roofline, "roofline_dual_path": dual, "stages": fam,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -41,6 +41,13 @@ typedef struct bsrnn_stream bsrnn_stream;
 
 int         bsrnn_abi_version(void);
 const char* bsrnn_last_error(void);
+/* How the matrix products are evaluated, e.g. "gemm=fp16x2 lstm=fp16x2" (measurement / logging only).
+ * Inputs, outputs, state and accumulation are float32 in every mode; the modes differ in which matrix pipe
+ * carries the products: "f32" = v_mfma_f32_*_f32 (exact fp32 fma chains), "fp16x2" / "bf16x3" = fp32 operands
+ * split into 2 fp16 / 3 bf16 pieces and multiplied on the 16-bit matrix cores with fp32 accumulation
+ * (error at the level of fp32 rounding noise).  Selected once per process by the environment
+ * variables BSRNN_GEMM (f32 | fp16x2 | bf16x3) and BSRNN_LSTM (f32 | fp16x2); default fp16x2 for both. */
+const char* bsrnn_compute_mode(void);
 
 /* ---- construction -------------------------------------------------------------------
  * Replaces `BSRNN()` (bsrnn.py:328-376).  `widths` are band widths in bins, in order,

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbsrnn_hip.so")
 
 # Every symbol include/bsrnn_hip.h declares (tests/test_abi.py checks header == this list == the .so)
 SYMBOLS = [
-    "bsrnn_abi_version", "bsrnn_last_error", "bsrnn_create", "bsrnn_destroy", "bsrnn_n_bands", "bsrnn_device",
+    "bsrnn_abi_version", "bsrnn_last_error", "bsrnn_compute_mode", "bsrnn_create", "bsrnn_destroy", "bsrnn_n_bands", "bsrnn_device",
     "bsrnn_param_count", "bsrnn_param_info", "bsrnn_set_param", "bsrnn_get_param", "bsrnn_commit_params",
     "bsrnn_load_weights_file", "bsrnn_forward", "bsrnn_forward_recurrent", "bsrnn_forward_chunk", "bsrnn_dual_path",
     "bsrnn_stft", "bsrnn_istft", "bsrnn_separate", "bsrnn_stream_create", "bsrnn_stream_destroy", "bsrnn_stream_reset",
@@ -41,6 +41,7 @@ def _load():
     sig = {
         "bsrnn_abi_version": (C.c_int, []),
         "bsrnn_last_error": (C.c_char_p, []),
+        "bsrnn_compute_mode": (C.c_char_p, []),
         "bsrnn_create": (C.c_int, [C.c_int, C.POINTER(i32), i32, C.POINTER(vp)]),
         "bsrnn_destroy": (None, [vp]),
         "bsrnn_n_bands": (C.c_int, [vp]),
@@ -90,3 +91,8 @@ def check(rc):
 
 def stage_names():
     return [lib.bsrnn_stage_name(i).decode() for i in range(lib.bsrnn_stage_count())]
+
+
+def compute_mode():
+    """{'gemm': 'f32'|'fp16x2'|'bf16x3', 'lstm': 'f32'|'fp16x2'} as reported by the library."""
+    return dict(kv.split("=") for kv in lib.bsrnn_compute_mode().decode().split())

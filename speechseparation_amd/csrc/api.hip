@@ -427,6 +427,14 @@ extern "C" {
 
 int bsrnn_abi_version(void) { return BSRNN_ABI_VERSION; }
 const char* bsrnn_last_error(void) { return g_err; }
+const char* bsrnn_compute_mode(void)
+{
+    static char buf[64];
+    const int g = gemm_mode(), l = lstm_mode();
+    snprintf(buf, sizeof buf, "gemm=%s lstm=%s", g == GEMM_F32 ? "f32" : (g == GEMM_FP16X2 ? "fp16x2" : "bf16x3"),
+             l == LSTM_F32 ? "f32" : "fp16x2");
+    return buf;
+}
 
 int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx** out)
 {

@@ -197,3 +197,34 @@ def test_errors_are_loud(model):
         model.forward_recurrent(torch.zeros((2, 2050), device="cuda"), torch.zeros((4, 2, 23, 64), device="cuda"))
     with pytest.raises(NativeError):
         model.stft(torch.zeros((1, 1000), device="cuda"))     # reflect padding needs n > 1024
+
+
+def test_compute_mode_is_reported():
+    from speechseparation_amd import _native
+    m = _native.compute_mode()
+    assert m["gemm"] in ("f32", "fp16x2", "bf16x3") and m["lstm"] in ("f32", "fp16x2")
+    print("compute mode:", m)
+
+
+@pytest.mark.parametrize("which,fix", [("model", "sd_default"), ("model_hot", "sd_hot")])
+def test_precision_is_at_fp32_rounding_level(which, fix, request):
+    """The split-precision modes (fp32 operands as 16-bit pieces on the f16/bf16 matrix cores) must be as
+    accurate as fp32 arithmetic itself: the distance of the HIP result to the float64 evaluation of the model
+    may not exceed the distance of the float32 oracle to it by more than a small factor."""
+    from oracle import bsrnn_numpy as orc
+    from speechseparation_amd import weights
+    m, sd = request.getfixturevalue(which), request.getfixturevalue(fix)
+    x = weights.synth_tensor((3, 2050, 24), seed=77, scale=1.0)
+    y64 = orc.forward(sd, x, dtype=np.float64)
+    y32 = orc.forward(sd, x, dtype=np.float32)
+    y = t2n(m(torch.from_numpy(x).cuda()))
+    e_hip, e_f32 = maxabs(y, y64), maxabs(y32, y64)
+    print("forward: |hip - f64| %.2e   |f32 oracle - f64| %.2e   (max|y| %.2f)" % (e_hip, e_f32, np.abs(y64).max()))
+    assert e_hip <= 3 * e_f32 + 1e-7
+    z = weights.synth_tensor((3, 24, 12, 64), seed=78, scale=1.0)
+    z64, _ = orc.dual_path(sd, z.astype(np.float64), None, np.float64)
+    z32, _ = orc.dual_path(sd, z, None, np.float32)
+    zo, _ = m.dual_path(torch.from_numpy(z).cuda())
+    e_hip, e_f32 = maxabs(t2n(zo), z64), maxabs(z32, z64)
+    print("dual path: |hip - f64| %.2e   |f32 oracle - f64| %.2e   (max|z| %.2f)" % (e_hip, e_f32, np.abs(z64).max()))
+    assert e_hip <= 3 * e_f32 + 1e-7
