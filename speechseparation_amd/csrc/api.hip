@@ -582,12 +582,19 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     std::vector<size_t> jw, jb, jwp;     // arena offsets, patched to pointers after upload
     // split-precision modes: the same matrix as NP 16-bit planes [NP][N][Kp] (gemm.hip), packed into arena floats
     const int gmode = gemm_mode();
-    auto put_planes = [&](const std::vector<float>& wp) -> size_t {
+    auto put_planes = [&](const std::vector<float>& wp, int N, int Kp) -> size_t {
         if (gmode == GEMM_F32 || wp.empty()) return 0;
-        std::vector<uint16_t> pl(wp.size() * gmode + 1);
-        split_planes_host(wp.data(), wp.size(), gmode, pl.data());
-        std::vector<float> packed((wp.size() * gmode + 1) / 2);
-        memcpy(packed.data(), pl.data(), wp.size() * gmode * sizeof(uint16_t));
+        std::vector<uint16_t> pl;
+        if (gmode == GEMM_FP16X2) {          // slab-interleaved pieces, rows padded to a multiple of 32 (gemm_h2_kernel)
+            const int K32 = (Kp + 31) & ~31;
+            pl.assign((size_t)N * K32 * 2 + 1, 0);
+            pack_h2_slabs_host(wp.data(), N, Kp, Kp, K32, pl.data());
+        } else {
+            pl.assign(wp.size() * gmode + 1, 0);
+            split_planes_host(wp.data(), wp.size(), gmode, pl.data());
+        }
+        std::vector<float> packed(pl.size() / 2 + 1);
+        memcpy(packed.data(), pl.data(), pl.size() * sizeof(uint16_t));
         return ar.put(packed);
     };
     std::vector<int2> tiles;
@@ -609,7 +616,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         for (int r = 0; r < N; ++r) memcpy(&wp[(size_t)r * Kp], &w.data[(size_t)r * Kd], Kd * sizeof(float));
         jw.push_back(ar.put(wp));
         jb.push_back(ar.put(bi.data));
-        jwp.push_back(put_planes(wp));
+        jwp.push_back(put_planes(wp, N, Kp));
         jobs.push_back(j);
     };
     auto begin_slot = [&](int slot) { c->job0[slot] = (int)jobs.size(); c->tile0[slot] = (int)tiles.size(); };

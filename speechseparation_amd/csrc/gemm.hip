@@ -31,6 +31,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+#ifndef GEMM_H2_SCHED
+#define GEMM_H2_SCHED 1
+#endif
 #ifndef GEMM_BK
 #define GEMM_BK 32
 #endif
@@ -280,7 +283,8 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
 //     0: fp32 activations are split by the staging threads;
 //   * ACC2: separate accumulators for the leading term and the corrections (required for NP = 2);
 //   * PF: slabs in flight (register staging sets).
-// ABL (measurement only): 1 = no global loads after the first slab, 2 = no MFMA.
+// ABL (measurement only): 1 = no global loads after the first slab, 2 = no MFMA, 4 = epilogue without its global
+// stores, 8 = no epilogue at all (one store per wave keeps the accumulators alive).
 // =====================================================================================
 template <int NP> struct Piece;
 template <> struct Piece<3> {
@@ -315,10 +319,14 @@ template <> struct Piece<2> {
     static __device__ __forceinline__ v16f mfma(const T8 a, const T8 b, const v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-template <int EPI, int NP, int NT, int AMODE, int BMODE, int ACC2, int PF = 1, int ABL = 0>
-__global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(GemmLaunch g)
+template <int EPI, int NP, int NT, int AMODE, int BMODE, int ACC2, int PF = 1, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : (NT == 1 ? 3 : 2))) void gemm_split_kernel(GemmLaunch g)
 {
     static_assert(NP == 3 || ACC2 == 1, "fp16x2 keeps the scaled corrections in their own accumulator");
+    static_assert(NW == 4 || (NW == 8 && NT == 2), "waves: 2 x 2 (each 64 x 32 NT), or 2 x 4 on the 128-wide tile (each 64 x 32)");
+    constexpr int TT = 64 * NW, WN = NW / 2, NJ = 2 * NT / WN;     // threads, waves along N, 32-column tiles per wave
+    constexpr int RP = TT / 4, RS = TT / 8;                       // rows per staging pass: 16-bit planes / fp32
+    constexpr int APP = BM / RP, BPP = 64 * NT / RP, ASP = BM / RS, BSP = 64 * NT / RS;
     typedef Piece<NP> PC;
     typedef typename PC::T hT;
     typedef typename PC::T4 h4;
@@ -350,13 +358,13 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, r32 = lane & 31;
-    const int wcol = 32 * NT * wn;                 // first column of this wave inside the tile
-    float bias[NT];
-    bool live[NT];
+    const int wcol = 32 * NJ * wn;                 // first column of this wave inside the tile
+    float bias[NJ];
+    bool live[NJ];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int nc = n0 + wcol + 32 * j + r32;
         bias[j] = ((gcf)job.bias)[nc < N ? nc : N - 1];
         live[j] = (n0 + wcol + 32 * j) < N;
@@ -371,23 +379,23 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
     const gcf W = (gcf)job.W;
     const gch Xp = (gch)g.Xp + job.x_off;
     const gcf X = (gcf)(g.X + job.x_off);
-    unsigned oap[2], oa[4], obp[NT], ob[2 * NT];
+    unsigned oap[APP], oa[ASP], obp[BPP], ob[BSP];
     // register staging sets: PF slabs are in flight (the loads of slab k + PF are issued before the MFMAs of slab k)
-    struct Stage { v4f ra[4]; v4f rb[2 * NT]; h8 rap[2][NP]; h8 rbp[NT][NP]; };
+    struct Stage { v4f ra[ASP]; v4f rb[BSP]; h8 rap[APP][NP]; h8 rbp[BPP][NP]; };
     Stage st[PF];
     if (AMODE == 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { int row = m0 + p_row + 64 * i; row = row < M ? row : M - 1; oap[i] = (unsigned)row * (unsigned)g.ldx + p_k; }
+        for (int i = 0; i < APP; ++i) { int row = m0 + p_row + RP * i; row = row < M ? row : M - 1; oap[i] = (unsigned)row * (unsigned)g.ldx + p_k; }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { int row = m0 + s_row + 32 * i; row = row < M ? row : M - 1; oa[i] = (unsigned)row * (unsigned)g.ldx + s_k; }
+        for (int i = 0; i < ASP; ++i) { int row = m0 + s_row + RS * i; row = row < M ? row : M - 1; oa[i] = (unsigned)row * (unsigned)g.ldx + s_k; }
     }
     if (BMODE == 1) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) { int row = n0 + p_row + 64 * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * (unsigned)K + p_k; }
+        for (int i = 0; i < BPP; ++i) { int row = n0 + p_row + RP * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * (unsigned)K + p_k; }
     } else {
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) { int row = n0 + s_row + 32 * i; row = row < N ? row : N - 1; ob[i] = (unsigned)row * (unsigned)K + s_k; }
+        for (int i = 0; i < BSP; ++i) { int row = n0 + s_row + RS * i; row = row < N ? row : N - 1; ob[i] = (unsigned)row * (unsigned)K + s_k; }
     }
     // full slabs take plain loads: any arithmetic on the loaded registers here (tail masking) would make the
     // compiler wait for the loads right away, in front of the MFMA cluster they are meant to overlap with
@@ -395,21 +403,21 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
         if (k0 + 32 <= K) {
             if (BMODE == 1) {
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < BPP; ++i)
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) t.rbp[i][pl] = *(gch8)(Wp + (obp[i] + k0 + pl * wplane));
             } else {
 #pragma unroll
-                for (int i = 0; i < 2 * NT; ++i) t.rb[i] = *(gcf4)(W + (ob[i] + k0));
+                for (int i = 0; i < BSP; ++i) t.rb[i] = *(gcf4)(W + (ob[i] + k0));
             }
             if (AMODE == 1) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < APP; ++i)
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) t.rap[i][pl] = *(gch8)(Xp + pl * g.xp_plane + (oap[i] + k0));
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t.ra[i] = *(gcf4)(X + (oa[i] + k0));
+                for (int i = 0; i < ASP; ++i) t.ra[i] = *(gcf4)(X + (oa[i] + k0));
             }
             return;
         }
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
         const float zm = sin ? 1.f : 0.f;
         if (BMODE == 1) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+            for (int i = 0; i < BPP; ++i)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {
                     t.rbp[i][pl] = *(gch8)(Wp + (obp[i] + pk + pl * wplane));
@@ -426,11 +434,11 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
                 }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2 * NT; ++i) t.rb[i] = *(gcf4)(W + (ob[i] + sk)) * zm;
+            for (int i = 0; i < BSP; ++i) t.rb[i] = *(gcf4)(W + (ob[i] + sk)) * zm;
         }
         if (AMODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < APP; ++i)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {
                     t.rap[i][pl] = *(gch8)(Xp + pl * g.xp_plane + (oap[i] + pk));
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
                 }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) t.ra[i] = *(gcf4)(X + (oa[i] + sk)) * zm;
+            for (int i = 0; i < ASP; ++i) t.ra[i] = *(gcf4)(X + (oa[i] + sk)) * zm;
         }
     };
     auto put_split = [&](const v4f v, int o) {
@@ -450,31 +458,31 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
     auto put = [&](const Stage& t) {
         if (AMODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < APP; ++i)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    *reinterpret_cast<h8*>(&smemh[pl * PLANE + (p_row + 64 * i) * PS + p_k]) = t.rap[i][pl];
+                    *reinterpret_cast<h8*>(&smemh[pl * PLANE + (p_row + RP * i) * PS + p_k]) = t.rap[i][pl];
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) put_split(t.ra[i], (s_row + 32 * i) * PS + s_k);
+            for (int i = 0; i < ASP; ++i) put_split(t.ra[i], (s_row + RS * i) * PS + s_k);
         }
         if (BMODE == 1) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+            for (int i = 0; i < BPP; ++i)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    *reinterpret_cast<h8*>(&smemh[pl * PLANE + (BM + p_row + 64 * i) * PS + p_k]) = t.rbp[i][pl];
+                    *reinterpret_cast<h8*>(&smemh[pl * PLANE + (BM + p_row + RP * i) * PS + p_k]) = t.rbp[i][pl];
         } else {
 #pragma unroll
-            for (int i = 0; i < 2 * NT; ++i) put_split(t.rb[i], (BM + s_row + 32 * i) * PS + s_k);
+            for (int i = 0; i < BSP; ++i) put_split(t.rb[i], (BM + s_row + RS * i) * PS + s_k);
         }
     };
 
-    v16f acc[2][NT][NACC];
+    v16f acc[2][NJ][NACC];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int a = 0; a < NACC; ++a) acc[i][j][a] = (v16f){0};
 
@@ -486,11 +494,11 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h8 b[NT][NP], a[2][NP];
+            h8 b[NJ][NP], a[2][NP];
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j][pl] = *reinterpret_cast<const h8*>(&smemh[pl * PLANE + ob0 + 32 * j * PS + 16 * ks]);
+                for (int j = 0; j < NJ; ++j) b[j][pl] = *reinterpret_cast<const h8*>(&smemh[pl * PLANE + ob0 + 32 * j * PS + 16 * ks]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) a[i][pl] = *reinterpret_cast<const h8*>(&smemh[pl * PLANE + oa0 + 32 * i * PS + 16 * ks]);
             }
@@ -498,11 +506,11 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) { acc[i][0][0][pl] += (float)a[i][pl][0]; acc[i][NT - 1][0][3 + pl] += (float)b[NT - 1][pl][1]; }
+                    for (int pl = 0; pl < NP; ++pl) { acc[i][0][0][pl] += (float)a[i][pl][0]; acc[i][NJ - 1][0][3 + pl] += (float)b[NJ - 1][pl][1]; }
                 continue;
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 if (j > 0 && !live[j]) continue;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -525,16 +533,34 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
 #pragma unroll
     for (int u = 0; u < PF; ++u)
         if (32 * u < K) gload(st[u], 32 * u);
+    // ABL & 16 (measurement only): 100 MHz stamps per phase, summed per wave, written to g.tap (tools/gemm_planes_bench.hip)
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+    auto stamp = [&](int k) { if (ABL & 16) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
+    unsigned long long c_begin = 0, t_begin = 0;
+    if (ABL & 16) { tq = t_begin = __builtin_amdgcn_s_memrealtime(); c_begin = __builtin_amdgcn_s_memtime(); }
     for (int k0 = 0; k0 < K; k0 += 32 * PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int kk = k0 + 32 * u;
             if (u > 0 && kk >= K) break;
             __syncthreads();
+            stamp(0);
             put(st[u]);
+            stamp(1);
             __syncthreads();
+            stamp(2);
             if (!(ABL & 1) && kk + 32 * PF < K) gload(st[u], kk + 32 * PF);
+            stamp(3);
             compute();
+            stamp(4);
+        }
+    }
+    if (ABL & 16) {
+        if (lane == 0) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(g.tap) + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) d[k] = tp[k];
+            d[5] = K / 32; d[6] = __builtin_amdgcn_s_memtime() - c_begin; d[7] = __builtin_amdgcn_s_memrealtime() - t_begin + 1;
         }
     }
 
@@ -544,12 +570,23 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
     typedef const v4f __attribute__((address_space(1)))* gc4;
     typedef v4f __attribute__((address_space(1)))* g4;
     constexpr float LO_SCALE = NP == 2 ? 1.f / 2048.f : 1.f;
+    if (ABL & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) t += acc[i][j][a][0] + acc[i][j][a][7];
+        if (t == 123.456f) g.Y[0] = t;
+        return;
+    }
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         __syncthreads();
         if (wm == hh) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 if (!live[j]) continue;
                 const int col = wcol + 32 * j + r32;
                 const bool in = n0 + col < N;
@@ -565,10 +602,31 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
             }
         }
         __syncthreads();
+        if (g.out_mode == 1) {
+            // fp32 output only: 16-byte units, consecutive lanes store consecutive 16 bytes of a row (whole lines)
+            constexpr int UPR4 = BN / 4;
+#pragma unroll
+            for (int u = 0; u < 64 * UPR4 / TT; ++u) {
+                const int idx = tid + TT * u;
+                const int row = idx / UPR4, c4 = idx % UPR4;
+                const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
+                if (m < M && n < N) {
+                    v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
+                    if (EPI == EPI_RES || EPI == EPI_MASK) v += *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
+                    if (EPI == EPI_MASK) {
+                        if (g.tap) *(g4)((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
+                        v *= *(gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
+                    }
+                    if (!(ABL & 4) || v[0] == 123.456f) *(g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
+                }
+            }
+            continue;
+        }
+        // plane output (and optionally fp32 beside it): units of 8 columns, one 16-byte store per plane
         constexpr int UPR = BN / 8;
 #pragma unroll
-        for (int u = 0; u < 64 * UPR / 256; ++u) {
-            const int idx = tid + 256 * u;
+        for (int u = 0; u < 64 * UPR / TT; ++u) {
+            const int idx = tid + TT * u;
             const int row = idx / UPR, c8 = idx % UPR;
             const int m = m0 + 64 * hh + row, n = n0 + 8 * c8;
             if (m < M && n < N) {
@@ -602,8 +660,261 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_split_kernel(Gemm
     }
 }
 
-template <int NP, int NT, int AMODE, int BMODE, int ACC2, int PF = 1, int ABL = 0>
+template <int NP, int NT, int AMODE, int BMODE, int ACC2, int PF = 1, int ABL = 0, int NW = 4>
 static void launch_gemm_split(const GemmLaunch& g_in, hipStream_t stream)
+{
+    GemmLaunch g = g_in;
+    const int m_tiles = (g.M + BM - 1) / BM;
+    g.mchunk = gemm_mchunk(m_tiles);
+    const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
+    dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(64 * NW);
+    switch (g.epilogue) {
+    case EPI_LINEAR: hipLaunchKernelGGL((gemm_split_kernel<EPI_LINEAR, NP, NT, AMODE, BMODE, ACC2, PF, ABL, NW>), grid, block, 0, stream, g); break;
+    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_split_kernel<EPI_LEAKY, NP, NT, AMODE, BMODE, ACC2, PF, ABL, NW>), grid, block, 0, stream, g); break;
+    case EPI_RES:    hipLaunchKernelGGL((gemm_split_kernel<EPI_RES, NP, NT, AMODE, BMODE, ACC2, PF, ABL, NW>), grid, block, 0, stream, g); break;
+    default:         hipLaunchKernelGGL((gemm_split_kernel<EPI_MASK, NP, NT, AMODE, BMODE, ACC2, PF, ABL, NW>), grid, block, 0, stream, g); break;
+    }
+}
+
+// =====================================================================================
+// fp16x2 product kernel, pipelined.  Same arithmetic as gemm_split_kernel<NP = 2, AMODE 0, BMODE 1, ACC2> (fp32
+// activations split on the fly, weights as two fp16 planes, hi / lo accumulators), different main loop.  In-kernel
+// stamps of that kernel (tools/gemm_planes_bench.hip, GEMM_TRACE) show a 1.6 us slab of which the MFMAs are 0.37:
+// every wave runs  barrier - split + ds_write - barrier - global-load issue - ds_read + MFMA  in sequence.  Here
+//   * LDS holds TWO stages; a wave splits slab k+1 into stage (k+1)&1 while the MFMAs of slab k (stage k&1) are
+//     in the matrix pipe, and there is ONE barrier per slab;
+//   * the split / ds_write / global-load instructions are placed after the MFMAs they should hide behind and
+//     interleaved with them by sched_group_barrier (one MFMA, then a few VALU / LDS / VMEM instructions);
+//   * rows are 64 bytes without padding, 16-byte units XOR-swizzled with (row >> 2) & 3, which keeps both the
+//     ds_read_b128 fragment reads and the stage at 32 KB (two stages + two workgroups per CU fit in 160 KB).
+// =====================================================================================
+template <int NVALU>
+__device__ __forceinline__ void sched_slice()
+{
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA, then behind it
+    __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);      //   VALU (the split)
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          //   one LDS write
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          //   one global load
+}
+
+template <int EPI, int NT, int ABL = 0>
+__global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLaunch g)
+{
+    typedef _Float16 hT;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef const h8 __attribute__((address_space(1)))* gch8;
+    typedef const hT __attribute__((address_space(1)))* gch;
+    typedef const v4f __attribute__((address_space(1)))* gcf4;
+    constexpr int BN = 64 * NT;
+    constexpr int PLANE = (BM + BN) * 32;           // halves per piece and stage: A rows then B rows, 64-byte rows
+    constexpr int STAGE = 2 * PLANE;
+    constexpr int ES = BN + 4;
+    __shared__ __attribute__((aligned(16))) hT smemh[2 * STAGE];
+    static_assert(2 * STAGE * 2 >= 64 * ES * 4, "epilogue staging must fit");
+
+    const int m_tiles = (g.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
+    const int mchunk = g.mchunk;
+    const int per_chunk = mchunk * g.n_tiles;
+    const int chunk = (lidx / per_chunk) * 8 + xcd;
+    const int rem = lidx % per_chunk;
+    const int m_tile = chunk * mchunk + rem % mchunk;
+    if (m_tile >= m_tiles) return;
+    const int2 tj = g.tiles[rem / mchunk];
+    const GemmJob job = g.jobs[tj.x];
+    const int n0 = tj.y * BN;
+    const int m0 = m_tile * BM;
+    const int N = job.N, K = job.K, M = g.M;       // K is a multiple of 8
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, r32 = lane & 31;
+    const int wcol = 32 * NT * wn;
+    float bias[NT];
+    bool live[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nc = n0 + wcol + 32 * j + r32;
+        bias[j] = ((gcf)job.bias)[nc < N ? nc : N - 1];
+        live[j] = (n0 + wcol + 32 * j) < N;
+    }
+
+    // staging: A fp32 in float4 units (8 per row, 32 rows per pass), B planes in 16-byte units (4 per row, 64 rows per pass)
+    const int p_row = tid >> 2, p_kq = tid & 3;
+    const int s_row = tid >> 3, s_k4 = tid & 7;
+    const gch Wp = (gch)job.Wp;
+    const gcf X = (gcf)(g.X + job.x_off);
+    // weights: [N][K32 / 32][2 pieces][32] fp16 (split_host.h, pack_h2_slabs_host): the two pieces of a slab of a row
+    // are one 128-byte line; rows are zero-padded to K32, so the weight side needs no tail masking
+    const unsigned wrow = (unsigned)((K + 31) & ~31) * 2;
+    unsigned oa[4], obp[NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int row = m0 + s_row + 32 * i; row = row < M ? row : M - 1; oa[i] = (unsigned)row * (unsigned)g.ldx + 4 * s_k4; }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { int row = n0 + p_row + 64 * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * wrow + 8 * p_kq; }
+    v4f ra[4];
+    h8 rbp[NT][2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) rbp[i][pl] = *(gch8)(Wp + (obp[i] + 2 * k0 + 32 * pl));
+        if (k0 + 32 <= K) {          // plain loads: no arithmetic on the registers until they are written to LDS
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + k0));
+            return;
+        }
+        const bool sin = k0 + 4 * s_k4 < K;
+        const int sk = sin ? k0 : -4 * s_k4;
+        const float zm = sin ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + sk)) * zm;
+    };
+    // LDS offsets (halves) of this thread's staging units; 16-byte unit kq of row r sits at unit kq ^ ((r >> 2) & 3)
+    int wa[4], wb[NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = s_row + 32 * i; wa[i] = r * 32 + (((s_k4 >> 1) ^ ((r >> 2) & 3)) * 8) + (s_k4 & 1) * 4; }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { const int r = BM + p_row + 64 * i; wb[i] = r * 32 + ((p_kq ^ ((r >> 2) & 3)) * 8); }
+    auto put_a = [&](hT* st, int i) {
+        h4 p[2];
+        Piece<2>::split(ra[i], p);
+        *reinterpret_cast<h4*>(&st[wa[i]]) = p[0];
+        *reinterpret_cast<h4*>(&st[PLANE + wa[i]]) = p[1];
+    };
+    auto put_b = [&](hT* st, int i) {
+        *reinterpret_cast<h8*>(&st[wb[i]]) = rbp[i][0];
+        *reinterpret_cast<h8*>(&st[PLANE + wb[i]]) = rbp[i][1];
+    };
+
+    v16f acc[2][NT][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { acc[i][j][0] = (v16f){0}; acc[i][j][1] = (v16f){0}; }
+
+    // fragment offsets: lane (r = l & 31, h = l >> 5) holds k = 16 ks + 8 h .. + 7, i.e. unit 2 ks + h
+    const int swz = (r32 >> 2) & 3;
+    const int fa = (64 * wm + r32) * 32, fb = (BM + wcol + r32) * 32;
+    const int fu[2] = {((0 + half) ^ swz) * 8, ((2 + half) ^ swz) * 8};
+
+    if (K > 0) {
+        gload(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) put_a(smemh, i);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) put_b(smemh, i);
+        if (K > 32) gload(32);
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const hT* const cur = smemh + ((k0 >> 5) & 1) * STAGE;
+        hT* const nxt = smemh + (((k0 >> 5) + 1) & 1) * STAGE;
+        const bool more = k0 + 32 < K;           // registers hold slab k0 + 32
+        if (live[0]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 b[NT][2], a[2][2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) b[j][pl] = *reinterpret_cast<const h8*>(&cur[pl * PLANE + fb + 32 * j * 32 + fu[ks]]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a[i][pl] = *reinterpret_cast<const h8*>(&cur[pl * PLANE + fa + 32 * i * 32 + fu[ks]]);
+                }
+                if (!(ABL & 2)) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        if (j > 0 && !live[j]) continue;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j][1], 0, 0, 0);
+                            acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j][1], 0, 0, 0);
+                            acc[i][j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j][0], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { acc[i][0][0][ks] += (float)a[i][0][0] + (float)a[i][1][1]; acc[i][NT - 1][1][ks] += (float)b[NT - 1][0][0] + (float)b[NT - 1][1][1]; }
+                }
+                // the next slab's staging rides behind this half's MFMAs: A rows after ks = 0, B rows and the
+                // global loads of the slab after that behind ks = 1
+                if (more) {
+                    if (ks == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) put_a(nxt, i);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) put_b(nxt, i);
+                    }
+                }
+                if (ks == 1 && !(ABL & 1) && k0 + 64 < K) gload(k0 + 64);
+#if GEMM_H2_SCHED
+                // 6 NT MFMAs per half: after each one, a slice of the VALU / LDS-write / VMEM work
+#pragma unroll
+                for (int q = 0; q < 6 * NT; ++q) {
+                    if (ks == 0) sched_slice<8>(); else sched_slice<2>();
+                }
+#endif
+            }
+        } else if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) put_a(nxt, i);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) put_b(nxt, i);
+            if (!(ABL & 1) && k0 + 64 < K) gload(k0 + 64);
+        }
+        __syncthreads();
+    }
+
+    // epilogue through LDS, fp32 output (16-byte units, whole lines per row)
+    float* const sE = reinterpret_cast<float*>(smemh);
+    typedef const v4f __attribute__((address_space(1)))* gc4;
+    typedef v4f __attribute__((address_space(1)))* g4;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if (hh) __syncthreads();
+        if (wm == hh) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!live[j]) continue;
+                const int col = wcol + 32 * j + r32;
+                const bool in = n0 + col < N;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float v = (acc[i][j][0][reg] + (1.f / 2048.f) * acc[i][j][1][reg]) + bias[j];
+                        if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
+                        if (!in) v = 0.f;
+                        sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + col] = v;
+                    }
+            }
+        }
+        __syncthreads();
+        constexpr int UPR4 = BN / 4;
+#pragma unroll
+        for (int u = 0; u < 64 * UPR4 / 256; ++u) {
+            const int idx = tid + 256 * u;
+            const int row = idx / UPR4, c4 = idx % UPR4;
+            const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
+            if (m < M && n < N) {
+                v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
+                if (EPI == EPI_RES || EPI == EPI_MASK) v += *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
+                if (EPI == EPI_MASK) {
+                    if (g.tap) *(g4)((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
+                    v *= *(gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
+                }
+                *(g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
+            }
+        }
+    }
+}
+
+template <int NT, int ABL = 0>
+static void launch_gemm_h2(const GemmLaunch& g_in, hipStream_t stream)
 {
     GemmLaunch g = g_in;
     const int m_tiles = (g.M + BM - 1) / BM;
@@ -611,10 +922,10 @@ static void launch_gemm_split(const GemmLaunch& g_in, hipStream_t stream)
     const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
     dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(256);
     switch (g.epilogue) {
-    case EPI_LINEAR: hipLaunchKernelGGL((gemm_split_kernel<EPI_LINEAR, NP, NT, AMODE, BMODE, ACC2, PF, ABL>), grid, block, 0, stream, g); break;
-    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_split_kernel<EPI_LEAKY, NP, NT, AMODE, BMODE, ACC2, PF, ABL>), grid, block, 0, stream, g); break;
-    case EPI_RES:    hipLaunchKernelGGL((gemm_split_kernel<EPI_RES, NP, NT, AMODE, BMODE, ACC2, PF, ABL>), grid, block, 0, stream, g); break;
-    default:         hipLaunchKernelGGL((gemm_split_kernel<EPI_MASK, NP, NT, AMODE, BMODE, ACC2, PF, ABL>), grid, block, 0, stream, g); break;
+    case EPI_LINEAR: hipLaunchKernelGGL((gemm_h2_kernel<EPI_LINEAR, NT, ABL>), grid, block, 0, stream, g); break;
+    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_h2_kernel<EPI_LEAKY, NT, ABL>), grid, block, 0, stream, g); break;
+    case EPI_RES:    hipLaunchKernelGGL((gemm_h2_kernel<EPI_RES, NT, ABL>), grid, block, 0, stream, g); break;
+    default:         hipLaunchKernelGGL((gemm_h2_kernel<EPI_MASK, NT, ABL>), grid, block, 0, stream, g); break;
     }
 }
 
@@ -653,8 +964,8 @@ void launch_gemm(const GemmLaunch& g, hipStream_t stream)
     if (g.M <= 0 || g.n_tiles <= 0) return;
     switch (gemm_mode()) {
     case GEMM_FP16X2:
-        if (g.tile_n == 128) launch_gemm_split<2, 2, 0, 1, 1, 1>(g, stream);
-        else launch_gemm_split<2, 1, 0, 1, 1, 1>(g, stream);
+        if (g.tile_n == 128) launch_gemm_h2<2>(g, stream);
+        else launch_gemm_h2<1>(g, stream);
         return;
     case GEMM_BF16X3:
         if (g.tile_n == 128) launch_gemm_split<3, 2, 0, 1, 0, 2>(g, stream);

@@ -55,6 +55,22 @@ inline void split_planes_host(const float* src, size_t n, int np, uint16_t* plan
         }
     }
 }
+// fp16x2 weights for the pipelined GEMM kernel: [N][K32 / 32][2 pieces][32] - both pieces of a 32-deep slab of a row
+// share one 128-byte line, so a k-step fetches exactly one line per weight row.  w is [N][ldw] fp32 with zero padding
+// up to K32 (a multiple of 32) provided by the caller through `K` (columns >= K read as zero).
+inline void pack_h2_slabs_host(const float* w, int N, int K, int ldw, int K32, uint16_t* out)
+{
+    for (int r = 0; r < N; ++r)
+        for (int k = 0; k < K32; ++k) {
+            const float v = k < K ? w[(size_t)r * ldw + k] : 0.f;
+            uint16_t pc[2];
+            split_planes_host(&v, 1, 2, pc);
+            uint16_t* o = out + ((size_t)r * (K32 / 32) + k / 32) * 64 + (k % 32);
+            o[0] = pc[0];
+            o[32] = pc[1];
+        }
+}
+
 inline float join_planes_host(const uint16_t* planes, size_t n, size_t i, int np)
 {
     if (np == 3) return (bf16_to_float(planes[i]) + bf16_to_float(planes[n + i])) + bf16_to_float(planes[2 * n + i]);

@@ -30,6 +30,7 @@ int main(int argc, char** argv)
     for (int i = 0; i < nb; ++i) {
         GemmJob j = {};
         j.N = j.K = 2 * widths[i];
+        if (const char* kc = getenv("KCAP")) j.K = std::min(j.K, atoi(kc));
         j.x_off = j.y_off = 2 * off;
         off += widths[i];
         woff.push_back(wtot);
@@ -46,7 +47,7 @@ int main(int argc, char** argv)
         for (int t = 0; t < (jobs[i].N + 127) / 128; ++t) tiles128.push_back(make_int2(i, t));
     }
     float *dW, *dX, *dY, *dY2;
-    uint16_t *dWp, *dXp, *dYp, *dWp16, *dXp16;
+    uint16_t *dWp, *dXp, *dYp, *dWp16, *dXp16, *dWq16;
     const size_t xn = (size_t)M * LD;
     CK(hipMalloc(&dW, wtot * 4));
     CK(hipMalloc(&dWp, wtot * 3 * 2));
@@ -69,6 +70,14 @@ int main(int argc, char** argv)
     CK(hipMemcpy(dWp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
     for (int i = 0; i < nb; ++i) split_planes_host(&h[woff[i]], (size_t)jobs[i].N * jobs[i].K, 2, &hp[2 * woff[i]]);
     CK(hipMemcpy(dWp16, hp.data(), wtot * 2 * 2, hipMemcpyHostToDevice));
+    // slab-interleaved fp16x2 weights for the pipelined kernel (rows padded to multiples of 32)
+    std::vector<size_t> qoff;
+    size_t qtot = 0;
+    for (int i = 0; i < nb; ++i) { qoff.push_back(qtot); qtot += (size_t)jobs[i].N * ((jobs[i].K + 31) & ~31) * 2; }
+    std::vector<uint16_t> hq(qtot + 8);
+    for (int i = 0; i < nb; ++i) pack_h2_slabs_host(&h[woff[i]], jobs[i].N, jobs[i].K, jobs[i].K, (jobs[i].K + 31) & ~31, &hq[qoff[i]]);
+    CK(hipMalloc(&dWq16, hq.size() * 2));
+    CK(hipMemcpy(dWq16, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
     std::vector<float> hx(xn);
     for (auto& v : hx) v = rand() / (float)RAND_MAX - 0.5f;
     CK(hipMemcpy(dX, hx.data(), xn * 4, hipMemcpyHostToDevice));
@@ -83,7 +92,7 @@ int main(int argc, char** argv)
         jobs[i].W = dW + woff[i]; jobs[i].bias = dW + woff[i] + (size_t)jobs[i].N * jobs[i].K;
         jobs[i].Wp = dWp + 3 * woff[i];
     }
-    GemmJob *dJ, *dJ16; int2 *dT, *dT128;
+    GemmJob *dJ, *dJ16, *dJq; int2 *dT, *dT128;
     CK(hipMalloc(&dT128, tiles128.size() * sizeof(int2)));
     CK(hipMemcpy(dT128, tiles128.data(), tiles128.size() * sizeof(int2), hipMemcpyHostToDevice));
     CK(hipMalloc(&dJ, jobs.size() * sizeof(GemmJob)));
@@ -92,6 +101,9 @@ int main(int argc, char** argv)
     for (int i = 0; i < nb; ++i) jobs[i].Wp = dWp16 + 2 * woff[i];
     CK(hipMalloc(&dJ16, jobs.size() * sizeof(GemmJob)));
     CK(hipMemcpy(dJ16, jobs.data(), jobs.size() * sizeof(GemmJob), hipMemcpyHostToDevice));
+    for (int i = 0; i < nb; ++i) jobs[i].Wp = dWq16 + qoff[i];
+    CK(hipMalloc(&dJq, jobs.size() * sizeof(GemmJob)));
+    CK(hipMemcpy(dJq, jobs.data(), jobs.size() * sizeof(GemmJob), hipMemcpyHostToDevice));
     CK(hipMemcpy(dT, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
     GemmLaunch g = {};
     g.jobs = dJ; g.tiles = dT; g.n_tiles = (int)tiles.size(); g.tile_n = 64;
@@ -103,36 +115,35 @@ int main(int argc, char** argv)
     GemmLaunch h1 = g1; h1.jobs = dJ16; h1.Xp = dXp16;       // fp16x2 operands
     GemmLaunch h2 = g2; h2.jobs = dJ16; h2.Xp = dXp16;
     GemmLaunch h2p = h2; h2p.out_mode = 2;
+    GemmLaunch q1 = h1; q1.jobs = dJq;                       // pipelined kernel: slab-interleaved weights
+    GemmLaunch q2 = h2; q2.jobs = dJq;
     double flop = 0;
     for (auto& j : jobs) flop += 2.0 * j.N * j.K * M;
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    constexpr int NV = 14;
-    const char* names[NV] = {"fp32 mfma (product kernel)", "bf16x3  64: A fly, B planes", "bf16x3 128: A fly, B planes, PF2", "fp16x2  64: A fly, B fly",
-                             "fp16x2  64: A fly, B planes", "fp16x2  64: A planes, B planes", "fp16x2 128: A fly, B planes", "fp16x2 128: A fly, B planes, PF2",
-                             "fp16x2 128: A planes, B planes", "fp16x2 128: A planes, B planes, PF2", "fp16x2 128: planes, PF2, no gload", "fp16x2 128: planes, PF2, no mfma",
-                             "fp16x2 128: planes, PF2 -> planes", "fp16x2  64: A planes, B planes, PF2"};
+    constexpr int NV = 12;
+    const char* names[NV] = {"fp32 mfma (product kernel)", "fp16x2  64: A fly, B planes", "fp16x2 128: A fly, B planes (product)", "fp16x2 128: 8 waves",
+                             "fp16x2 128: product, no global stores", "fp16x2 128: product, no epilogue", "fp16x2 128: no gload, no epilogue", "fp16x2 128: no mfma, no epilogue",
+                             "fp16x2 128 pipelined", "fp16x2  64 pipelined", "fp16x2 128 pipelined, no gload", "fp16x2 128 pipelined, no mfma"};
     std::vector<float> t[NV];
     for (int rep = 0; rep < 12; ++rep)
         for (int v = 0; v < NV; ++v) {
             CK(hipEventRecord(a, s));
             switch (v) {
             case 0: launch_gemm_nt<1, 0, 1, 4>(g, s); break;
-            case 1: launch_gemm_split<3, 1, 0, 1, 0>(g1, s); break;
-            case 2: launch_gemm_split<3, 2, 0, 1, 0, 2>(g2, s); break;
-            case 3: launch_gemm_split<2, 1, 0, 0, 1>(h1, s); break;
-            case 4: launch_gemm_split<2, 1, 0, 1, 1>(h1, s); break;
-            case 5: launch_gemm_split<2, 1, 1, 1, 1>(h1, s); break;
-            case 6: launch_gemm_split<2, 2, 0, 1, 1>(h2, s); break;
-            case 7: launch_gemm_split<2, 2, 0, 1, 1, 2>(h2, s); break;
-            case 8: launch_gemm_split<2, 2, 1, 1, 1>(h2, s); break;
-            case 9: launch_gemm_split<2, 2, 1, 1, 1, 2>(h2, s); break;
-            case 10: launch_gemm_split<2, 2, 1, 1, 1, 2, 1>(h2, s); break;
-            case 11: launch_gemm_split<2, 2, 1, 1, 1, 2, 2>(h2, s); break;
-            case 12: launch_gemm_split<2, 2, 1, 1, 1, 2>(h2p, s); break;
-            default: launch_gemm_split<2, 1, 1, 1, 1, 2>(h1, s); }
+            case 1: launch_gemm_split<2, 1, 0, 1, 1>(h1, s); break;
+            case 2: launch_gemm_split<2, 2, 0, 1, 1>(h2, s); break;
+            case 3: launch_gemm_split<2, 2, 0, 1, 1, 1, 0, 8>(h2, s); break;
+            case 4: launch_gemm_split<2, 2, 0, 1, 1, 1, 4>(h2, s); break;
+            case 5: launch_gemm_split<2, 2, 0, 1, 1, 1, 8>(h2, s); break;
+            case 6: launch_gemm_split<2, 2, 0, 1, 1, 1, 9>(h2, s); break;
+            case 7: launch_gemm_split<2, 2, 0, 1, 1, 1, 10>(h2, s); break;
+            case 8: launch_gemm_h2<2>(q2, s); break;
+            case 9: launch_gemm_h2<1>(q1, s); break;
+            case 10: launch_gemm_h2<2, 1>(q2, s); break;
+            default: launch_gemm_h2<2, 2>(q2, s); }
             CK(hipEventRecord(b, s));
             CK(hipEventSynchronize(b));
             float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -143,6 +154,30 @@ int main(int argc, char** argv)
         std::sort(t[v].begin(), t[v].end());
         const float med = t[v][t[v].size() / 2];
         printf("%-36s median %.1f us  min %.1f us  -> %.1f TFLOP/s-equivalent\n", names[v], med * 1e3, t[v][0] * 1e3, flop / (med * 1e-3) / 1e12);
+    }
+    if (getenv("GEMM_TRACE")) {        // phase times of the product variant, summed over all waves of all workgroups
+        const int m_tiles = (M + BM - 1) / BM, mc = gemm_mchunk(m_tiles);
+        const int nblk = 8 * (((m_tiles + mc - 1) / mc + 7) / 8) * mc * h2.n_tiles;
+        unsigned long long* dTr;
+        CK(hipMalloc(&dTr, (size_t)nblk * 4 * 64));
+        CK(hipMemset(dTr, 0, (size_t)nblk * 4 * 64));
+        GemmLaunch gt = h2;
+        gt.tap = reinterpret_cast<float*>(dTr);
+        launch_gemm_split<2, 2, 0, 1, 1, 1, 16>(gt, s);
+        CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> ht((size_t)nblk * 4 * 8);
+        CK(hipMemcpy(ht.data(), dTr, ht.size() * 8, hipMemcpyDeviceToHost));
+        double sum[5] = {0, 0, 0, 0, 0}, ksteps = 0, cyc = 0, rt = 0;
+        for (size_t i = 0; i < (size_t)nblk * 4; ++i)
+            if (ht[8 * i + 7]) {
+                for (int k = 0; k < 5; ++k) sum[k] += ht[8 * i + k];
+                ksteps += ht[8 * i + 5];
+                if (ht[8 * i + 5] >= 16) { cyc += ht[8 * i + 6]; rt += ht[8 * i + 7] - 1; }
+            }
+        printf("in-kernel clock over the main loops (s_memtime / s_memrealtime): %.2f GHz\n", cyc / rt * 0.1);
+        const char* nm[5] = {"barrier 1 (wait for the other waves' MFMAs)", "split + ds_write issue", "barrier 2 (LDS writes landed)", "global load issue", "ds_read + MFMA"};
+        printf("phase times per wave and k-step (ns), %0.f wave-k-steps:\n", ksteps);
+        for (int k = 0; k < 5; ++k) printf("  %-46s %7.0f\n", nm[k], sum[k] * 10.0 / ksteps);
     }
     // numerics against the fp32-MFMA kernel: bf16x3 (fp32 out), fp16x2 (fp32 out), fp16x2 plane output recombined
     launch_gemm_nt<1, 0, 1, 4>(g, s);
@@ -160,7 +195,9 @@ int main(int argc, char** argv)
     };
     launch_gemm_split<3, 2, 0, 1, 0, 2>(g2, s); diff("bf16x3 128 (1 acc) vs fp32 mfma");
     launch_gemm_split<2, 2, 0, 1, 1, 2>(h2, s); diff("fp16x2 128, A fly, B planes vs fp32 mfma");
-    launch_gemm_split<2, 1, 1, 1, 1, 2>(h1, s); diff("fp16x2 64, planes vs fp32 mfma");
+    launch_gemm_split<2, 2, 0, 1, 1, 1, 0, 8>(h2, s); diff("fp16x2 128, 8 waves vs fp32 mfma");
+    launch_gemm_h2<2>(q2, s); diff("fp16x2 128 pipelined vs fp32 mfma");
+    launch_gemm_h2<1>(q1, s); diff("fp16x2 64 pipelined vs fp32 mfma");
     launch_gemm_split<2, 2, 1, 1, 1, 2>(h2p, s);
     CK(hipStreamSynchronize(s));
     {
