@@ -586,9 +586,9 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         if (gmode == GEMM_F32 || wp.empty()) return 0;
         std::vector<uint16_t> pl;
         if (gmode == GEMM_FP16X2) {          // slab-interleaved pieces, rows padded to a multiple of 32 (gemm_h2_kernel)
-            const int K32 = (Kp + 31) & ~31;
-            pl.assign((size_t)N * K32 * 2 + 1, 0);
-            pack_h2_slabs_host(wp.data(), N, Kp, Kp, K32, pl.data());
+            const int K32 = (Kp + 31) & ~31, wrow = h2_row_stride(K32);
+            pl.assign((size_t)N * wrow + 1, 0);
+            pack_h2_slabs_host(wp.data(), N, Kp, Kp, K32, wrow, pl.data());
         } else {
             pl.assign(wp.size() * gmode + 1, 0);
             split_planes_host(wp.data(), wp.size(), gmode, pl.data());
@@ -617,6 +617,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         jw.push_back(ar.put(wp));
         jb.push_back(ar.put(bi.data));
         jwp.push_back(put_planes(wp, N, Kp));
+        j.wrow = h2_row_stride((Kp + 31) & ~31);
         jobs.push_back(j);
     };
     auto begin_slot = [&](int slot) { c->job0[slot] = (int)jobs.size(); c->tile0[slot] = (int)tiles.size(); };

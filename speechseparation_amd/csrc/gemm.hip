@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace bsrnn {
 
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     const gcf X = (gcf)(g.X + job.x_off);
     // weights: [N][K32 / 32][2 pieces][32] fp16 (split_host.h, pack_h2_slabs_host): the two pieces of a slab of a row
     // are one 128-byte line; rows are zero-padded to K32, so the weight side needs no tail masking
-    const unsigned wrow = (unsigned)((K + 31) & ~31) * 2;
+    const unsigned wrow = (unsigned)job.wrow;
     unsigned oa[4], obp[NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { int row = m0 + s_row + 32 * i; row = row < M ? row : M - 1; oa[i] = (unsigned)row * (unsigned)g.ldx + 4 * s_k4; }
@@ -771,6 +772,14 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
         const float zm = sin ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + sk)) * zm;
+    };
+    auto gload_full = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) rbp[i][pl] = *(gch8)(Wp + (obp[i] + 2 * k0 + 32 * pl));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + k0));
     };
     // LDS offsets (halves) of this thread's staging units; 16-byte unit kq of row r sits at unit kq ^ ((r >> 2) & 3)
     int wa[4], wb[NT];
@@ -809,11 +818,15 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
         if (K > 32) gload(32);
     }
     __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    // One slab.  FAST = steady state (every column tile of the wave live, two more full slabs to come): no branches,
+    // so the whole body is one basic block and the staging can be interleaved with the MFMAs; the generic form
+    // handles ragged tiles and the last slabs.
+    auto step = [&](auto fast_tag, const int k0) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         const hT* const cur = smemh + ((k0 >> 5) & 1) * STAGE;
         hT* const nxt = smemh + (((k0 >> 5) + 1) & 1) * STAGE;
-        const bool more = k0 + 32 < K;           // registers hold slab k0 + 32
-        if (live[0]) {
+        const bool more = FAST || k0 + 32 < K;     // registers hold slab k0 + 32
+        if (FAST || live[0]) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 h8 b[NT][2], a[2][2];
@@ -827,7 +840,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
                 if (!(ABL & 2)) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        if (j > 0 && !live[j]) continue;
+                        if (!FAST && j > 0 && !live[j]) continue;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j][1], 0, 0, 0);
@@ -850,12 +863,16 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
                         for (int i = 0; i < NT; ++i) put_b(nxt, i);
                     }
                 }
-                if (ks == 1 && !(ABL & 1) && k0 + 64 < K) gload(k0 + 64);
+                if (ks == 1 && !(ABL & 1)) {
+                    if (FAST) gload_full(k0 + 64);
+                    else if (k0 + 64 < K) gload(k0 + 64);
+                }
 #if GEMM_H2_SCHED
-                // 6 NT MFMAs per half: after each one, a slice of the VALU / LDS-write / VMEM work
+                if (FAST) {
 #pragma unroll
-                for (int q = 0; q < 6 * NT; ++q) {
-                    if (ks == 0) sched_slice<8>(); else sched_slice<2>();
+                    for (int q = 0; q < 6 * NT; ++q) {
+                        if (ks == 0) sched_slice<8>(); else sched_slice<2>();
+                    }
                 }
 #endif
             }
@@ -867,6 +884,12 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
             if (!(ABL & 1) && k0 + 64 < K) gload(k0 + 64);
         }
         __syncthreads();
+    };
+    {
+        int k0 = 0;
+        if (live[NT - 1])
+            for (; k0 + 96 <= K; k0 += 32) step(std::true_type(), k0);
+        for (; k0 < K; k0 += 32) step(std::false_type(), k0);
     }
 
     // epilogue through LDS, fp32 output (16-byte units, whole lines per row)

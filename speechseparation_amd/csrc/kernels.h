@@ -23,6 +23,7 @@ struct GemmJob {
     int y_off;           // column offset of the output inside a Y row
     int r_off;           // column offset inside the residual row (EPI_RES, EPI_MASK)
     int m_off;           // column offset inside the multiplier / mask-tap row (EPI_MASK)
+    int wrow;            // fp16x2 slab format: 16-bit elements between consecutive weight rows of Wp
 };
 
 enum GemmEpilogue {

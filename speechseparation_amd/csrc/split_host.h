@@ -58,14 +58,19 @@ inline void split_planes_host(const float* src, size_t n, int np, uint16_t* plan
 // fp16x2 weights for the pipelined GEMM kernel: [N][K32 / 32][2 pieces][32] - both pieces of a 32-deep slab of a row
 // share one 128-byte line, so a k-step fetches exactly one line per weight row.  w is [N][ldw] fp32 with zero padding
 // up to K32 (a multiple of 32) provided by the caller through `K` (columns >= K read as zero).
-inline void pack_h2_slabs_host(const float* w, int N, int K, int ldw, int K32, uint16_t* out)
+// Rows are `wrow` 16-bit elements apart (>= 2 K32; see h2_row_stride).
+inline int h2_row_stride(int K32)
+{
+    return 2 * K32;     // (an extra line per row against L2 channel camping was measured: no effect on gfx950)
+}
+inline void pack_h2_slabs_host(const float* w, int N, int K, int ldw, int K32, int wrow, uint16_t* out)
 {
     for (int r = 0; r < N; ++r)
         for (int k = 0; k < K32; ++k) {
             const float v = k < K ? w[(size_t)r * ldw + k] : 0.f;
             uint16_t pc[2];
             split_planes_host(&v, 1, 2, pc);
-            uint16_t* o = out + ((size_t)r * (K32 / 32) + k / 32) * 64 + (k % 32);
+            uint16_t* o = out + (size_t)r * wrow + (k / 32) * 64 + (k % 32);
             o[0] = pc[0];
             o[32] = pc[1];
         }

@@ -73,9 +73,14 @@ int main(int argc, char** argv)
     // slab-interleaved fp16x2 weights for the pipelined kernel (rows padded to multiples of 32)
     std::vector<size_t> qoff;
     size_t qtot = 0;
-    for (int i = 0; i < nb; ++i) { qoff.push_back(qtot); qtot += (size_t)jobs[i].N * ((jobs[i].K + 31) & ~31) * 2; }
+    const int rowpad = getenv("ROWPAD") ? atoi(getenv("ROWPAD")) : -1;     // -1: the library's rule, else extra 16-bit elements per row
+    for (int i = 0; i < nb; ++i) {
+        const int K32 = (jobs[i].K + 31) & ~31;
+        jobs[i].wrow = rowpad < 0 ? h2_row_stride(K32) : 2 * K32 + rowpad;
+        qoff.push_back(qtot); qtot += (size_t)jobs[i].N * jobs[i].wrow;
+    }
     std::vector<uint16_t> hq(qtot + 8);
-    for (int i = 0; i < nb; ++i) pack_h2_slabs_host(&h[woff[i]], jobs[i].N, jobs[i].K, jobs[i].K, (jobs[i].K + 31) & ~31, &hq[qoff[i]]);
+    for (int i = 0; i < nb; ++i) pack_h2_slabs_host(&h[woff[i]], jobs[i].N, jobs[i].K, jobs[i].K, (jobs[i].K + 31) & ~31, jobs[i].wrow, &hq[qoff[i]]);
     CK(hipMalloc(&dWq16, hq.size() * 2));
     CK(hipMemcpy(dWq16, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
     std::vector<float> hx(xn);
