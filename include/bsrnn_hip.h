@@ -35,6 +35,7 @@ extern "C" {
 #define BSRNN_EHIP        3   /* HIP runtime error */
 #define BSRNN_EIO         4   /* weight file problem */
 #define BSRNN_ENOKEY      5   /* unknown parameter key */
+#define BSRNN_ERANGE      6   /* an activation left the range of the split-precision mode (|a| > 65504), see below */
 
 typedef struct bsrnn_ctx bsrnn_ctx;
 typedef struct bsrnn_stream bsrnn_stream;
@@ -46,7 +47,10 @@ const char* bsrnn_last_error(void);
  * carries the products: "f32" = v_mfma_f32_*_f32 (exact fp32 fma chains), "fp16x2" / "bf16x3" = fp32 operands
  * split into 2 fp16 / 3 bf16 pieces and multiplied on the 16-bit matrix cores with fp32 accumulation
  * (error at the level of fp32 rounding noise).  Selected once per process by the environment
- * variables BSRNN_GEMM (f32 | fp16x2 | bf16x3) and BSRNN_LSTM (f32 | fp16x2); default fp16x2 for both. */
+ * variables BSRNN_GEMM (f32 | fp16x2 | bf16x3) and BSRNN_LSTM (f32 | fp16x2); default fp16x2 for both.
+ * Range: the fp16x2 mode represents operands up to |a| = 65504 (spectra of audio in [-1, 1] stay below 1024).
+ * A larger activation saturates; the kernels notice, and the NEXT call on the context (or bsrnn_sync) fails
+ * with BSRNN_ERANGE instead of returning a silently different result.  Rescale the input or use "f32". */
 const char* bsrnn_compute_mode(void);
 
 /* ---- construction -------------------------------------------------------------------

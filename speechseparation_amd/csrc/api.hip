@@ -75,7 +75,8 @@ struct bsrnn_ctx {
     int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT], tile_n[NSLOT];
 
     const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
-    const void *bandW16[2][2], *timeW16[2];                     // fp16x2 pieces in MFMA operand order (lstm.hip)
+    const void *bandW16[2][2], *timeW16[2];
+    int *h_range = nullptr, *d_range = nullptr;    // range guard of the fp16x2 kernels: host-mapped word the kernels set                     // fp16x2 pieces in MFMA operand order (lstm.hip)
     float* d_tables = nullptr;
     int* d_colmap = nullptr;
     FftTables tb;
@@ -296,6 +297,7 @@ void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ld
     GemmLaunch g;
     memset(&g, 0, sizeof g);
     g.out_mode = 1;
+    g.range_flag = c->d_range;
     g.jobs = c->d_jobs + c->job0[slot];
     g.tiles = c->d_tiles + c->tile0[slot];
     g.n_tiles = c->ntiles[slot];
@@ -355,8 +357,8 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     case MS_BAND0: case MS_BAND1: {   // BandwiseLSTM: N = M sequences of length K   bsrnn.py:138-153
         const int blk = stage == MS_BAND1;
         StageScope sc(c, ST_BAND_LSTM, s);
-        launch_band_lstm(p.Z0, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, s);
-        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, s);
+        launch_band_lstm(p.Z0, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
+        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);
         break;
     }
     case MS_BANDFC0: case MS_BANDFC1: {
@@ -370,7 +372,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         StageScope sc(c, ST_TIME_LSTM, s);
         launch_time_lstm(p.Z1, p.H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
                          p.state_in ? p.state_in + blk * p.state_slab : nullptr,
-                         p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, s);
+                         p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, c->d_range, s);
         break;
     }
     case MS_TIMEFC0: case MS_TIMEFC1: {
@@ -412,12 +414,21 @@ int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T
     return 0;
 }
 
+int check_range(bsrnn_ctx* c)
+{
+    if (c->h_range && *(volatile int*)c->h_range) {
+        *(volatile int*)c->h_range = 0;
+        return fail(BSRNN_ERANGE, "an earlier call fed the fp16x2 matrix path an activation beyond +-65504 (or NaN/Inf); its "
+                                  "results are saturated - rescale the input or set BSRNN_GEMM=f32 BSRNN_LSTM=f32");
+    }
+    return 0;
+}
 int check_ready(bsrnn_ctx* c)
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (!c->committed) return fail(BSRNN_ESTATE, "bsrnn_commit_params() has not been called");
     HIP_TRY(hipSetDevice(c->device));
-    return 0;
+    return check_range(c);
 }
 
 }  // namespace
@@ -461,6 +472,11 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
     }
     c->LDA = ao; c->LDP = imax(po, 8);
     build_inventory(c);
+    {   // range-guard word: pinned host memory the fp16x2 kernels can set and the host can read without a sync
+        hipError_t e = hipHostMalloc((void**)&c->h_range, sizeof(int), hipHostMallocMapped);
+        if (e == hipSuccess) { *c->h_range = 0; e = hipHostGetDevicePointer((void**)&c->d_range, c->h_range, 0); }
+        if (e != hipSuccess) { c->h_range = nullptr; c->d_range = nullptr; (void)hipGetLastError(); }
+    }
     if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(1, std::min(MAX_PARTS, atoi(e)));
     if (const char* e = getenv("BSRNN_PART_LAG")) c->part_lag = std::max(0, std::min((int)MS_COUNT, atoi(e)));
     memset(c->acc_ms, 0, sizeof c->acc_ms);
@@ -525,6 +541,7 @@ void bsrnn_destroy(bsrnn_ctx* c)
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_colmap) (void)hipFree(c->d_colmap);
+    if (c->h_range) (void)hipHostFree(c->h_range);
     delete c;
 }
 
@@ -882,11 +899,11 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
     HIP_TRY(hipMemcpyAsync(c->Z0, z, nz * sizeof(float), hipMemcpyDeviceToDevice, s));
     const size_t slab = (size_t)2 * 2 * C * K * HID;
     for (int blk = 0; blk < 2; ++blk) {
-        launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, s);
-        launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, s);
+        launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
+        launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);
         gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
         launch_time_lstm(c->Z1, c->H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
-                         state_out ? state_out + blk * slab : nullptr, C, T, K, s);
+                         state_out ? state_out + blk * slab : nullptr, C, T, K, c->d_range, s);
         gemm_slot(c, BLK_FC1 + 2 * blk, c->H1, HID, c->Z0, HID, c->Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
     }
     HIP_TRY(hipMemcpyAsync(z_out, c->Z0, nz * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1171,7 +1188,7 @@ int bsrnn_sync(bsrnn_ctx* c, void* stream)
     if (!c) return fail(BSRNN_EARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return 0;
+    return check_range(c);
 }
 
 }  // extern "C"

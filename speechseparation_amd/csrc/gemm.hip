@@ -787,8 +787,11 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     for (int i = 0; i < 4; ++i) { const int r = s_row + 32 * i; wa[i] = r * 32 + (((s_k4 >> 1) ^ ((r >> 2) & 3)) * 8) + (s_k4 & 1) * 4; }
 #pragma unroll
     for (int i = 0; i < NT; ++i) { const int r = BM + p_row + 64 * i; wb[i] = r * 32 + ((p_kq ^ ((r >> 2) & 3)) * 8); }
+    float amax = 0.f;                             // largest |activation| staged by this thread (range guard)
     auto put_a = [&](hT* st, int i) {
         h4 p[2];
+        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ra[i][0]), __builtin_fabsf(ra[i][1])),
+                                                     __builtin_fmaxf(__builtin_fabsf(ra[i][2]), __builtin_fabsf(ra[i][3]))));
         Piece<2>::split(ra[i], p);
         *reinterpret_cast<h4*>(&st[wa[i]]) = p[0];
         *reinterpret_cast<h4*>(&st[PLANE + wa[i]]) = p[1];
@@ -891,6 +894,8 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
             for (; k0 + 96 <= K; k0 += 32) step(std::true_type(), k0);
         for (; k0 < K; k0 += 32) step(std::false_type(), k0);
     }
+
+    if (!(amax <= 65504.f) && g.range_flag) *g.range_flag = 1;     // also catches NaN / Inf inputs
 
     // epilogue through LDS, fp32 output (16-byte units, whole lines per row)
     float* const sE = reinterpret_cast<float*>(smemh);

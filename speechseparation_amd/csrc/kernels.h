@@ -51,6 +51,7 @@ struct GemmLaunch {
     const void* Xp; size_t xp_plane;   // input planes; null: X is fp32 and is split on the fly
     void* Yp; size_t yp_plane;         // output planes (written when out_mode & 2)
     int out_mode;                      // bit 0: write fp32 Y, bit 1: write planes Yp
+    int* range_flag;                   // fp16x2: set to 1 when an operand exceeded the fp16 range (may be null)
 };
 void launch_gemm(const GemmLaunch& g, hipStream_t stream);
 // How the Linear layers are evaluated (environment BSRNN_GEMM = f32 | fp16x2 | bf16x3, read once per process).
@@ -67,7 +68,7 @@ constexpr int GEMM_BM = 128;
 //   wpk16 (LSTM_FP16X2): the same matrix as two fp16 pieces in the f16 MFMA's B-operand order,
 //         [2 dir][4 wave][(IN+64)/32 blk][4 gate][2 piece][64 lane][8]
 void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      int N, int L, int IN, hipStream_t stream);
+                      int N, int L, int IN, int* range_flag, hipStream_t stream);
 // How the recurrent layers evaluate their gate products (environment BSRNN_LSTM = f32 | fp16x2, read once).
 enum LstmMode { LSTM_F32 = 0, LSTM_FP16X2 = 2 };
 int lstm_mode();
@@ -76,7 +77,7 @@ int lstm_mode();
 //   state_in/out [2 (h,c)][2 layer][R*K][64] or null
 //   wpk16 (LSTM_FP16X2): two fp16 pieces in B-operand order, [2 layer][4 wave][4 blk][4 gate][2 piece][64 lane][8]
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      const float* state_in, float* state_out, int R, int T, int K, hipStream_t stream);
+                      const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream);
 
 // ------------------------------------------------------------------ STFT / iSTFT / layout
 struct FftTables {           // device tables, built once per context (double precision on host)

@@ -179,7 +179,7 @@ __device__ __forceinline__ void split_h2(const float v, _Float16& p0, _Float16& 
 template <int IN, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __restrict__ xin, float* __restrict__ hout,
                                                               const uint4* __restrict__ wpk, const float* __restrict__ bias,
-                                                              int N, int L, unsigned long long* __restrict__ dbg)
+                                                              int N, int L, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg)
 {
     // measurement only (TRACE, tools/lstm_h2_trace.hip): 100 MHz stamps per phase, accumulated per wave
     unsigned long long tp[5] = {0, 0, 0, 0, 0}, tq = 0;
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
             dst[i] = *reinterpret_cast<const float4*>(xin + ((size_t)row * L + t) * IN + 4 * xr_c4[i]);
         }
     };
+    float amax = 0.f;                            // range guard: largest |x| this thread staged
     auto xstore = [&](int slot, const float4* src) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
             h4v p0, p1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                amax = __builtin_fmaxf(amax, __builtin_fabsf(v[e]));
                 const float cl = __builtin_fminf(__builtin_fmaxf(v[e], -65504.f), 65504.f);
                 _Float16 a, b2;
                 split_h2(cl, a, b2);
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         __syncthreads();
         stamp(4);
     }
+    if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
     if (TRACE && lane == 0 && blockIdx.x < 4 && blockIdx.y == 0) {
         unsigned long long* d = dbg + (blockIdx.x * 4 + wave) * 5;
 #pragma unroll
@@ -359,15 +362,15 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
 }
 
 void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      int N, int L, int IN, hipStream_t stream)
+                      int N, int L, int IN, int* range_flag, hipStream_t stream)
 {
     if (N <= 0 || L <= 0) return;
     dim3 grid((N + 15) / 16, 2), block(256);
     if (lstm_mode() == LSTM_FP16X2) {
         if (IN == 64)
-            hipLaunchKernelGGL(band_lstm_h2_kernel<64>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(band_lstm_h2_kernel<64>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, range_flag, (unsigned long long*)nullptr);
         else
-            hipLaunchKernelGGL(band_lstm_h2_kernel<128>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(band_lstm_h2_kernel<128>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, range_flag, (unsigned long long*)nullptr);
         return;
     }
     if (IN == 64)
@@ -562,7 +565,7 @@ template <bool TRACE = false>
 __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restrict__ zin, float* __restrict__ hout,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
                                                            const float* __restrict__ state_in, float* __restrict__ state_out,
-                                                           int R, int T, int K, unsigned long long* __restrict__ dbg)
+                                                           int R, int T, int K, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg)
 {
     unsigned long long tp[5] = {0, 0, 0, 0, 0}, tq = 0;       // measurement only, as in the band kernel
     auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
@@ -620,11 +623,13 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
         t = t < T ? t : T - 1;
         return *reinterpret_cast<const float4*>(zin + xs_base + (size_t)t * tstride);
     };
+    float amax = 0.f;                            // range guard
     auto chunk_store = [&](int chunk, float4 v) {
         const float f[4] = {v.x, v.y, v.z, v.w};
         h4v p0, p1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
             _Float16 a, b2;
             split_h2(__builtin_fminf(__builtin_fmaxf(f[e], -65504.f), 65504.f), a, b2);
             p0[e] = a; p1[e] = b2;
@@ -711,6 +716,7 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
         __syncthreads();
         stamp(3);
     }
+    if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
     if (TRACE && lane == 0 && blockIdx.x < 4) {
         unsigned long long* d = dbg + (blockIdx.x * 8 + wave) * 5;
 #pragma unroll
@@ -724,14 +730,14 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
 }
 
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      const float* state_in, float* state_out, int R, int T, int K, hipStream_t stream)
+                      const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream)
 {
     const int N = R * K;
     if (N <= 0 || T <= 0) return;
     dim3 grid((N + 3) / 4), block(512);
     if (lstm_mode() == LSTM_FP16X2) {
         hipLaunchKernelGGL(time_lstm_h2_kernel<false>, grid, block, 0, stream, zin, hout, (const uint4*)wpk16, bias, state_in, state_out, R, T, K,
-                           (unsigned long long*)nullptr);
+                           range_flag, (unsigned long long*)nullptr);
         return;
     }
     hipLaunchKernelGGL(time_lstm_kernel, grid, block, 0, stream, zin, hout, wpk, bias, state_in, state_out, R, T, K,

@@ -86,3 +86,28 @@ def test_long_sequence_causality(sd_default):
         assert maxabs(torch.cat(ys, 2).cpu().numpy(), y_off.cpu().numpy()) < 3e-5
         finals.append(state.cpu().numpy())
     assert maxabs(finals[0], finals[1]) < 2e-5 and maxabs(finals[0], finals[2]) < 2e-5
+
+
+def test_large_inputs_stay_accurate_and_out_of_range_is_loud(sd_default):
+    """The fp16x2 matrix path represents operands up to 65504.  Inside that range accuracy must not depend on
+    the magnitude (a spectrum scaled to |x| ~ 1e3, the ceiling for audio in [-1, 1]); beyond it the library
+    must not return a silently saturated result: the next call on the context fails with BSRNN_ERANGE."""
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import _native, weights
+    from speechseparation_amd._native import NativeError
+    m = make_model(sd_default)
+    x = weights.synth_tensor((2, 2050, 6), seed=5, scale=250.0)          # |x| up to ~1e3
+    ref = onp.forward(sd_default, x, dtype=np.float64)
+    y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    rel = maxabs(y, ref) / np.abs(ref).max()
+    print("scaled input: max|y| %.3g, relative error %.2e" % (np.abs(ref).max(), rel))
+    assert rel < 2e-6
+    if _native.compute_mode()["gemm"] != "fp16x2":
+        return
+    big = torch.from_numpy(x * 1e4).cuda()                              # |x| ~ 1e7: outside the fp16x2 range
+    m(big)
+    torch.cuda.synchronize()
+    with pytest.raises(NativeError, match="65504"):
+        m(torch.from_numpy(x).cuda())
+    y2 = m(torch.from_numpy(x).cuda()).cpu().numpy()                    # the flag is reported once; the context keeps working
+    assert np.array_equal(y2, y)

@@ -24,8 +24,8 @@ static int run_band(int N, int L)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, 0));
-        if (rep == 3) hipLaunchKernelGGL((band_lstm_h2_kernel<IN, true>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, dbg);
-        else hipLaunchKernelGGL((band_lstm_h2_kernel<IN, false>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, dbg);
+        if (rep == 3) hipLaunchKernelGGL((band_lstm_h2_kernel<IN, true>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, (int*)nullptr, dbg);
+        else hipLaunchKernelGGL((band_lstm_h2_kernel<IN, false>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, (int*)nullptr, dbg);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("band_lstm_h2<%d> N=%d L=%d launch %d: %.1f us\n", IN, N, L, rep, ms * 1e3);
@@ -60,8 +60,8 @@ static int run_time(int R, int T, int K)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, 0));
-        if (rep == 3) hipLaunchKernelGGL(time_lstm_h2_kernel<true>, dim3(R * K / 4), dim3(512), 0, 0, z, h, (const uint4*)w, b, (const float*)nullptr, (float*)nullptr, R, T, K, dbg);
-        else hipLaunchKernelGGL(time_lstm_h2_kernel<false>, dim3(R * K / 4), dim3(512), 0, 0, z, h, (const uint4*)w, b, (const float*)nullptr, (float*)nullptr, R, T, K, dbg);
+        if (rep == 3) hipLaunchKernelGGL(time_lstm_h2_kernel<true>, dim3(R * K / 4), dim3(512), 0, 0, z, h, (const uint4*)w, b, (const float*)nullptr, (float*)nullptr, R, T, K, (int*)nullptr, dbg);
+        else hipLaunchKernelGGL(time_lstm_h2_kernel<false>, dim3(R * K / 4), dim3(512), 0, 0, z, h, (const uint4*)w, b, (const float*)nullptr, (float*)nullptr, R, T, K, (int*)nullptr, dbg);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("time_lstm_h2 launch %d: %.1f us\n", rep, ms * 1e3);
