@@ -550,17 +550,24 @@ __global__ __launch_bounds__(512) void time_lstm_kernel(const float* __restrict_
 // =====================================================================================
 // Time-axis LSTM, split-precision variant (fp16x2 on v_mfma_f32_16x16x32_f16, as the band kernel above).
 // The fp32 kernel's step is bound by the 4x4x1 MFMA stream (2 waves x 128 MFMAs x 9.5 cycles per SIMD and
-// step); here a wave needs 48 MFMAs of 16 cycles.  Same decomposition (4 sequences per workgroup, waves 0-3
-// layer 0, waves 4-7 layer 1 one step behind, one barrier per step), different operand roles:
-//   A = activations, 16 rows of which row 4j carries sequence j (the other rows repeat it and are ignored),
-//   B = weights, tile g = gate g of the wave's 16 units (column n = unit 16w+n), resident in VGPRs,
-// so accumulator register 0 of lane (n, q = lane >> 4) is gate g of cell (unit 16w+n, sequence q): every lane
-// owns exactly one cell and its four gates, no cross-lane traffic.  x_t / h_t live in LDS as two fp16 planes in
-// [k / 8][sequence][8] order (fragment reads are conflict-free ds_read_b128, replicas read the same address).
-// Phase order per step, chosen so that the two waves of a SIMD keep its matrix pipe busy in turns:
-//   layer 0:  recurrent half (h0_{s-1})            -> cell(s)   -> input half of step s+1 (x_{s+1})
-//   layer 1:  input half (h0_{s-1}) + recurrent half (h1_{s-2}) -> cell(s-1)
+// step).  Same decomposition (4 sequences per workgroup, waves 0-3 layer 0, waves 4-7 layer 1, one barrier per
+// step), but the matrix work is organised around the 16-row tile of the f16 MFMA:
+//   * recurrent half (h_{t-1} W_hh, the sequential part): A = activations with row 4j = sequence j (the rows in
+//     between repeat it and are ignored), B = weights, tile g = gate g of the wave's 16 units (column n = unit
+//     16w+n), resident in VGPRs.  Accumulator register 0 of lane (n, q = lane >> 4) is gate g of cell
+//     (unit 16w+n, sequence q): every lane owns exactly one cell and its four gates, no cross-lane traffic.
+//   * input half (x_t W_ih for layer 0, h0_t W_ih for layer 1) does not depend on the layer's own recurrence,
+//     so FOUR time steps are batched into one MFMA group: A row 4j + r = (sequence j, step 4g + r) fills all
+//     16 rows, and register r of lane (n, q) is then the input pre-activation of this lane's own cell at step
+//     4g + r.  One group of 24 MFMAs per four steps instead of 24 per step; with the two-MFMA recurrent form
+//     below: 22 instead of 48 MFMAs per wave and step (matrix-pipe floor 0.34 instead of 0.73 us per step).  Layer 1 therefore runs four steps behind
+//     layer 0 (its input h0_{4g..4g+3} is complete after layer 0's step 4g+3); h0 lives in a ring of 8 steps.
+// x_t / h_t live in LDS as two fp16 planes in [k / 8][sequence][8] order per step (fragment reads are
+// conflict-free ds_read_b128; steps are 1088 bytes apart so that the four steps of a batched read hit
+// different banks).
 // =====================================================================================
+constexpr int TSTEP = 2 * 4 * HID + 32;       // halves per step slot in LDS: two pieces of [8][4][8] + 64 bytes of skew
+
 template <bool TRACE = false>
 __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restrict__ zin, float* __restrict__ hout,
                                                            const uint4* __restrict__ wpk, const float* __restrict__ bias,
@@ -569,9 +576,9 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
 {
     unsigned long long tp[5] = {0, 0, 0, 0, 0}, tq = 0;       // measurement only, as in the band kernel
     auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
-    __shared__ __attribute__((aligned(16))) _Float16 xpl[2][TCH][2][4 * HID];     // [chunk slot][step][piece][k/8][seq][8]
-    __shared__ __attribute__((aligned(16))) _Float16 h0pl[2][2][4 * HID];
-    __shared__ __attribute__((aligned(16))) _Float16 h1pl[2][2][4 * HID];
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[2 * TCH * TSTEP];     // [chunk slot][step in chunk]
+    __shared__ __attribute__((aligned(16))) _Float16 h0pl[8 * TSTEP];          // ring: h0_t in slot t & 7
+    __shared__ __attribute__((aligned(16))) _Float16 h1pl[2 * TSTEP];          // h1_t in slot t & 1
 
     const int N = R * K;
     const int n0 = blockIdx.x * 4;
@@ -600,15 +607,15 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
 #pragma unroll
     for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[layer * 256 + gte * 64 + unit];
 
-    const int hoff = ((unit >> 3) * 4 + q) * 8 + (unit & 7);      // where this lane's h goes inside a plane
+    const int hoff = ((unit >> 3) * 4 + q) * 8 + (unit & 7);      // where this lane's h goes inside a piece
     float c = state_in ? state_in[((size_t)(2 + layer) * N + nq) * HID + unit] : 0.f;
     {
         const float hinit = state_in ? state_in[((size_t)layer * N + nq) * HID + unit] : 0.f;
         _Float16 p0, p1;
         split_h2(hinit, p0, p1);
-        _Float16(*hb)[4 * HID] = layer ? h1pl[1] : h0pl[1];        // h_{-1} lives in slot 1
-        hb[0][hoff] = p0;
-        hb[1][hoff] = p1;
+        _Float16* hb = layer ? &h1pl[1 * TSTEP] : &h0pl[7 * TSTEP];   // h_{-1}: slot (-1) & 1 = 1, (-1) & 7 = 7
+        hb[hoff] = p0;
+        hb[4 * HID + hoff] = p1;
     }
 
     // x chunk staging: 8 steps x 4 sequences x 16 float4 = 512 float4, one per thread, split on the way into LDS
@@ -634,9 +641,9 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
             split_h2(__builtin_fminf(__builtin_fmaxf(f[e], -65504.f), 65504.f), a, b2);
             p0[e] = a; p1[e] = b2;
         }
-        const int o = ((xs_c4 >> 1) * 4 + xs_i) * 8 + (xs_c4 & 1) * 4;
-        *reinterpret_cast<h4v*>(&xpl[chunk & 1][xs_t][0][o]) = p0;
-        *reinterpret_cast<h4v*>(&xpl[chunk & 1][xs_t][1][o]) = p1;
+        _Float16* dst = &xpl[((chunk & 1) * TCH + xs_t) * TSTEP + ((xs_c4 >> 1) * 4 + xs_i) * 8 + (xs_c4 & 1) * 4];
+        *reinterpret_cast<h4v*>(dst) = p0;
+        *reinterpret_cast<h4v*>(dst + 4 * HID) = p1;
     };
     chunk_store(0, chunk_load(0));
     float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -644,77 +651,110 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
     __syncthreads();
 
     v4f hi[4], lo[4];
-    auto reset_acc = [&]() {
-#pragma unroll
-        for (int gte = 0; gte < 4; ++gte) { hi[gte] = (v4f){bs[gte], bs[gte], bs[gte], bs[gte]}; lo[gte] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-    };
-    // A fragment of this lane inside a 32-deep block of a plane: row l & 15 carries sequence (l & 15) >> 2
+    float pin[4][4];                              // [gate][step in group]: bias + input half of this lane's cell
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    // A fragments inside a 32-deep block of a piece: row l & 15 of the recurrent form carries sequence (l & 15) >> 2;
+    // in the batched form it carries (sequence (l & 15) >> 2, step (l & 15) & 3) of the group
     const int afrag = (q * 4 + (n >> 2)) * 8;
-    auto half_gemv = [&](const _Float16 (*src)[4 * HID], const int wofs) {
+    const int bstep = n & 3;
+    auto mfma_block = [&](const h8v a0, const h8v a1, const int wb) {
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[wb][gte][0], hi[gte], 0, 0, 0);
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[wb][gte][1], lo[gte], 0, 0, 0);
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[wb][gte][0], lo[gte], 0, 0, 0);
+    };
+    // recurrent half: src = one step slot.  Only rows 4j of the 16-row tile carry a sequence, so row 4j+1 is given
+    // the SECOND piece of the same sequence: one MFMA against w1 (first weight piece) then yields a1 w1 in register
+    // 0 and a2 w1 in register 1 of the owning lane, a second MFMA against w2 yields a1 w2 in register 0 - two
+    // MFMAs per (block, gate) instead of three, and one fragment read per block instead of two.
+    const int rfrag = afrag + ((n & 3) == 1 ? 4 * HID : 0);
+    auto recurrent = [&](const _Float16* src) {
+        h8v a[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) a[b] = *reinterpret_cast<const h8v*>(&src[b * 128 + rfrag]);
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) { hi[gte] = zero4; lo[gte] = zero4; }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[b], w[2 + b][gte][0], hi[gte], 0, 0, 0);
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[b], w[2 + b][gte][1], lo[gte], 0, 0, 0);
+        }
+    };
+    // input half of four consecutive steps; `src` = slot of the group's first step, the lane's step is src + bstep slots
+    auto batched_input = [&](const _Float16* src) {
+        const _Float16* mine = src + bstep * TSTEP;
         h8v a0[2], a1[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            a0[b] = *reinterpret_cast<const h8v*>(&src[0][b * 128 + afrag]);
-            a1[b] = *reinterpret_cast<const h8v*>(&src[1][b * 128 + afrag]);
+            a0[b] = *reinterpret_cast<const h8v*>(&mine[b * 128 + afrag]);
+            a1[b] = *reinterpret_cast<const h8v*>(&mine[4 * HID + b * 128 + afrag]);
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int gte = 0; gte < 4; ++gte) { hi[gte] = zero4; lo[gte] = zero4; }
 #pragma unroll
-            for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[wofs + b][gte][0], hi[gte], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) mfma_block(a0[b], a1[b], b);
 #pragma unroll
-            for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[wofs + b][gte][1], lo[gte], 0, 0, 0);
+        for (int gte = 0; gte < 4; ++gte)
 #pragma unroll
-            for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[b], w[wofs + b][gte][0], lo[gte], 0, 0, 0);
-        }
+            for (int r = 0; r < 4; ++r) pin[gte][r] = bs[gte] + (hi[gte][r] + lo[gte][r] * (1.f / 2048.f));
     };
-    auto cell = [&](int t) {
-        const float ig = fast_sigmoid(hi[0][0] + lo[0][0] * (1.f / 2048.f));
-        const float fg = fast_sigmoid(hi[1][0] + lo[1][0] * (1.f / 2048.f));
-        const float gg = fast_tanh(hi[2][0] + lo[2][0] * (1.f / 2048.f));
-        const float og = fast_sigmoid(hi[3][0] + lo[3][0] * (1.f / 2048.f));
+    auto cell = [&](int t, int r) {
+        // hi[g] = {a1 w1, a2 w1, -, -}, lo[g] = {a1 w2, -, -, -} of this lane's cell (see recurrent())
+        const float ig = fast_sigmoid(pin[0][r] + (hi[0][0] + (hi[0][1] + lo[0][0]) * (1.f / 2048.f)));
+        const float fg = fast_sigmoid(pin[1][r] + (hi[1][0] + (hi[1][1] + lo[1][0]) * (1.f / 2048.f)));
+        const float gg = fast_tanh(pin[2][r] + (hi[2][0] + (hi[2][1] + lo[2][0]) * (1.f / 2048.f)));
+        const float og = fast_sigmoid(pin[3][r] + (hi[3][0] + (hi[3][1] + lo[3][0]) * (1.f / 2048.f)));
         c = fg * c + ig * gg;
         hsel = og * fast_tanh(c);
         csel = c;
         _Float16 p0, p1;
         split_h2(hsel, p0, p1);
-        _Float16(*hb)[4 * HID] = layer ? h1pl[t & 1] : h0pl[t & 1];
-        hb[0][hoff] = p0;
-        hb[1][hoff] = p1;
+        _Float16* hb = layer ? &h1pl[(t & 1) * TSTEP] : &h0pl[(t & 7) * TSTEP];
+        hb[hoff] = p0;
+        hb[4 * HID + hoff] = p1;
         if (layer && nq_raw < N) hout[base_q + (size_t)t * tstride + unit] = hsel;
     };
+    auto xslot = [&](int t) { return &xpl[(((t / TCH) & 1) * TCH + (t % TCH)) * TSTEP]; };
 
-    if (layer == 0) { reset_acc(); half_gemv(xpl[0][0], 0); }       // input half of step 0
+    if (layer == 0) batched_input(xslot(0));      // group 0
     if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
-    for (int s = 0; s <= T; ++s) {
-        const int chunk = s / TCH, sin = s % TCH;
-        const bool have_next = (chunk + 1) * TCH < T;
-        if (sin == 0 && have_next) xnext = chunk_load(chunk + 1);
-        stamp(4);
-
-        if (layer == 0) {
-            if (s < T) {
-                half_gemv(h0pl[(s + 1) & 1], 2);                    // recurrent half, h0_{s-1}
-                stamp(1);
-                cell(s);
-                stamp(2);
-                reset_acc();
-                if (s + 1 < T) half_gemv(xpl[((s + 1) / TCH) & 1][(s + 1) % TCH], 0);   // input half of step s+1
-                stamp(0);
+    // iteration s: layer 0 computes step s, layer 1 computes step s - 4
+    for (int s4 = 0; s4 < T + 4; s4 += 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = s4 + r;
+            if (s >= T + 4) break;
+            const int chunk = s / TCH, sin = s % TCH;
+            const bool have_next = (chunk + 1) * TCH < T;
+            if (sin == 0 && have_next) xnext = chunk_load(chunk + 1);
+            stamp(4);
+            if (layer == 0) {
+                if (s < T) {
+                    recurrent(&h0pl[((s + 7) & 7) * TSTEP]);            // h0_{s-1}
+                    stamp(1);
+                    cell(s, r);
+                    stamp(2);
+                }
+                if (r == 3 && s + 1 < T) { batched_input(xslot(s + 1)); stamp(0); }     // next group: x_{s+1 .. s+4}
+            } else {
+                const int t = s - 4;
+                if (r == 0 && t >= 0 && t < T) { batched_input(&h0pl[(t & 7) * TSTEP]); stamp(0); }   // h0_{t .. t+3}
+                if (t >= 0 && t < T) {
+                    recurrent(&h1pl[((t + 1) & 1) * TSTEP]);             // h1_{t-1}
+                    stamp(1);
+                    cell(t, r);
+                    stamp(2);
+                }
             }
-        } else if (s >= 1) {
-            const int t = s - 1;
-            reset_acc();
-            half_gemv(h0pl[t & 1], 0);                              // input half, h0_t
-            stamp(0);
-            half_gemv(h1pl[(t + 1) & 1], 2);                        // recurrent half, h1_{t-1}
-            stamp(1);
-            cell(t);
-            stamp(2);
+            // x of the next chunk is first read by the batched input at the end of the iteration before its first step
+            if (sin == TCH - 2 && have_next) chunk_store(chunk + 1, xnext);
+            __syncthreads();
+            stamp(3);
         }
-        // x of the next chunk is first read in the iteration before its first step (layer 0's look-ahead)
-        if (sin == TCH - 2 && have_next) chunk_store(chunk + 1, xnext);
-        __syncthreads();
-        stamp(3);
     }
     if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
     if (TRACE && lane == 0 && blockIdx.x < 4) {
