@@ -901,9 +901,25 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     float* const sE = reinterpret_cast<float*>(smemh);
     typedef const v4f __attribute__((address_space(1)))* gc4;
     typedef v4f __attribute__((address_space(1)))* g4;
+    constexpr int UPR4 = BN / 4, NU = 64 * UPR4 / 256;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         if (hh) __syncthreads();
+        // residual / multiplier rows of this half are requested before the accumulators go through LDS, so their
+        // latency hides behind the staging and its barrier (the mask launch reads 134 MB this way)
+        v4f rv[NU], mv[NU];
+        if (EPI == EPI_RES || EPI == EPI_MASK) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = tid + 256 * u;
+                const int row = idx / UPR4, c4 = idx % UPR4;
+                int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
+                m = m < M ? m : M - 1;
+                n = n < N ? n : 0;
+                rv[u] = *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
+                if (EPI == EPI_MASK) mv[u] = *(gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
+            }
+        }
         if (wm == hh) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -922,18 +938,17 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
             }
         }
         __syncthreads();
-        constexpr int UPR4 = BN / 4;
 #pragma unroll
-        for (int u = 0; u < 64 * UPR4 / 256; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int idx = tid + 256 * u;
             const int row = idx / UPR4, c4 = idx % UPR4;
             const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
             if (m < M && n < N) {
                 v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
-                if (EPI == EPI_RES || EPI == EPI_MASK) v += *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
+                if (EPI == EPI_RES || EPI == EPI_MASK) v += rv[u];
                 if (EPI == EPI_MASK) {
                     if (g.tap) *(g4)((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
-                    v *= *(gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
+                    v *= mv[u];
                 }
                 *(g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
             }
