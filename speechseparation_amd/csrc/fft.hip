@@ -45,6 +45,10 @@ __device__ __forceinline__ float2* fft1024(float2* z0, float2* z1, const Twiddle
 {
     float2* src = z0;
     float2* dst = z1;
+#ifdef FFT_ABL_NOPASSES
+    __syncthreads();
+    return src;
+#endif
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         const int p = 1 << (2 * q);

@@ -742,26 +742,24 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
         live[j] = (n0 + wcol + 32 * j) < N;
     }
 
-    // staging: A fp32 in float4 units (8 per row, 32 rows per pass), B planes in 16-byte units (4 per row, 64 rows per pass)
-    const int p_row = tid >> 2, p_kq = tid & 3;
+    // staging: 8 threads per row, 32 rows per pass, whole 128-byte lines for both operands: A fp32 in float4 units,
+    // B as the 8 units of a weight row's slab (units 0-3 first piece, 4-7 second piece)
     const int s_row = tid >> 3, s_k4 = tid & 7;
     const gch Wp = (gch)job.Wp;
     const gcf X = (gcf)(g.X + job.x_off);
     // weights: [N][K32 / 32][2 pieces][32] fp16 (split_host.h, pack_h2_slabs_host): the two pieces of a slab of a row
     // are one 128-byte line; rows are zero-padded to K32, so the weight side needs no tail masking
     const unsigned wrow = (unsigned)job.wrow;
-    unsigned oa[4], obp[NT];
+    unsigned oa[4], obp[2 * NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { int row = m0 + s_row + 32 * i; row = row < M ? row : M - 1; oa[i] = (unsigned)row * (unsigned)g.ldx + 4 * s_k4; }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { int row = n0 + p_row + 64 * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * wrow + 8 * p_kq; }
+    for (int i = 0; i < 2 * NT; ++i) { int row = n0 + s_row + 32 * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * wrow + 8 * s_k4; }
     v4f ra[4];
-    h8 rbp[NT][2];
+    h8 rbp[2 * NT];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) rbp[i][pl] = *(gch8)(Wp + (obp[i] + 2 * k0 + 32 * pl));
+        for (int i = 0; i < 2 * NT; ++i) rbp[i] = *(gch8)(Wp + (obp[i] + 2 * k0));
         if (k0 + 32 <= K) {          // plain loads: no arithmetic on the registers until they are written to LDS
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + k0));
@@ -775,18 +773,16 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     };
     auto gload_full = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) rbp[i][pl] = *(gch8)(Wp + (obp[i] + 2 * k0 + 32 * pl));
+        for (int i = 0; i < 2 * NT; ++i) rbp[i] = *(gch8)(Wp + (obp[i] + 2 * k0));
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + k0));
     };
     // LDS offsets (halves) of this thread's staging units; 16-byte unit kq of row r sits at unit kq ^ ((r >> 2) & 3)
-    int wa[4], wb[NT];
+    int wa[4], wb[2 * NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int r = s_row + 32 * i; wa[i] = r * 32 + (((s_k4 >> 1) ^ ((r >> 2) & 3)) * 8) + (s_k4 & 1) * 4; }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { const int r = BM + p_row + 64 * i; wb[i] = r * 32 + ((p_kq ^ ((r >> 2) & 3)) * 8); }
+    for (int i = 0; i < 2 * NT; ++i) { const int r = BM + s_row + 32 * i; wb[i] = (s_k4 >> 2) * PLANE + r * 32 + (((s_k4 & 3) ^ ((r >> 2) & 3)) * 8); }
     float amax = 0.f;                             // largest |activation| staged by this thread (range guard)
     auto put_a = [&](hT* st, int i) {
         h4 p[2];
@@ -797,8 +793,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
         *reinterpret_cast<h4*>(&st[PLANE + wa[i]]) = p[1];
     };
     auto put_b = [&](hT* st, int i) {
-        *reinterpret_cast<h8*>(&st[wb[i]]) = rbp[i][0];
-        *reinterpret_cast<h8*>(&st[PLANE + wb[i]]) = rbp[i][1];
+        *reinterpret_cast<h8*>(&st[wb[i]]) = rbp[i];
     };
 
     v16f acc[2][NT][2];
@@ -817,7 +812,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
 #pragma unroll
         for (int i = 0; i < 4; ++i) put_a(smemh, i);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) put_b(smemh, i);
+        for (int i = 0; i < 2 * NT; ++i) put_b(smemh, i);
         if (K > 32) gload(32);
     }
     __syncthreads();
@@ -863,7 +858,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
                         for (int i = 0; i < 4; ++i) put_a(nxt, i);
                     } else {
 #pragma unroll
-                        for (int i = 0; i < NT; ++i) put_b(nxt, i);
+                        for (int i = 0; i < 2 * NT; ++i) put_b(nxt, i);
                     }
                 }
                 if (ks == 1 && !(ABL & 1)) {
@@ -883,7 +878,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
 #pragma unroll
             for (int i = 0; i < 4; ++i) put_a(nxt, i);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) put_b(nxt, i);
+            for (int i = 0; i < 2 * NT; ++i) put_b(nxt, i);
             if (!(ABL & 1) && k0 + 64 < K) gload(k0 + 64);
         }
         __syncthreads();
