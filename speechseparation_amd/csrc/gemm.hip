@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
                     for (int reg = 0; reg < 16; ++reg) {
                         float v = acc[i][jn][reg] + bias[jn];
                         if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
+                        if (ncol0 + 32 * jn >= N) v = 0.f;          // pad columns of the output segment are exactly zero
                         sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + my_col + 32 * jn] = v;
                     }
         }
@@ -249,8 +250,10 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
             const int idx = tid + 256 * u;
             const int row = idx / CPR, c4 = idx % CPR;
             const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
-            // a chunk that straddles N stays inside the band's 4-aligned segment: its pad columns only need to be finite
-            if (m < M && n < N) {
+            // Columns [N, round8(N)) are written too (as zeros): the next layer's K loop runs to round8(K) against
+            // zero weights, and a buffer shared by layers of different widths must not leak a stale (possibly
+            // non-finite) value of a wider layer into that product.
+            if (m < M && n < ((N + 7) & ~7)) {
                 v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
                 if (EPI == EPI_RES || EPI == EPI_MASK)
                     v += *reinterpret_cast<const v4f __attribute__((address_space(1)))*>((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
@@ -308,14 +311,16 @@ template <> struct Piece<2> {
     typedef _Float16 T;
     typedef _Float16 T4 __attribute__((ext_vector_type(4)));
     typedef _Float16 T8 __attribute__((ext_vector_type(8)));
+    // a1 = fp16(a) (RNE); a2 = fp16(2048 (a - a1)): a - a1 and the scaling are exact in fp32, so the fused form
+    // fma(-a1, 2048, 2048 a) rounds once, to the same value - two VALU instructions per element (v_pk_mul_f32 +
+    // v_fma_mix{lo,hi}_f16) instead of convert-back / subtract / multiply / convert.  |a| > 65504 makes a1
+    // infinite: callers track max |a| and raise the range flag (the result is invalid either way).
     static __device__ __forceinline__ void split(const v4f a, T4* p)
     {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float c = __builtin_fminf(__builtin_fmaxf(a[i], -65504.f), 65504.f);
-            p[0][i] = (_Float16)c;
-            p[1][i] = (_Float16)((c - (float)p[0][i]) * 2048.f);
-        }
+        for (int i = 0; i < 4; ++i) p[0][i] = (_Float16)a[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[1][i] = (_Float16)__builtin_fmaf(-(float)p[0][i], 2048.f, a[i] * 2048.f);
     }
     static __device__ __forceinline__ v16f mfma(const T8 a, const T8 b, const v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : (NT == 1 ? 3 : 2))) void ge
                 const int idx = tid + TT * u;
                 const int row = idx / UPR4, c4 = idx % UPR4;
                 const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
-                if (m < M && n < N) {
+                if (m < M && n < ((N + 7) & ~7)) {
                     v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
                     if (EPI == EPI_RES || EPI == EPI_MASK) v += *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
                     if (EPI == EPI_MASK) {
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : (NT == 1 ? 3 : 2))) void ge
             const int idx = tid + TT * u;
             const int row = idx / UPR, c8 = idx % UPR;
             const int m = m0 + 64 * hh + row, n = n0 + 8 * c8;
-            if (m < M && n < N) {
+            if (m < M && n < ((N + 7) & ~7)) {
                 v4f v0 = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8]);
                 v4f v1 = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8 + 4]);
                 if (EPI == EPI_RES || EPI == EPI_MASK) {
@@ -786,9 +791,15 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     float amax = 0.f;                             // largest |activation| staged by this thread (range guard)
     auto put_a = [&](hT* st, int i) {
         h4 p[2];
-        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ra[i][0]), __builtin_fabsf(ra[i][1])),
-                                                     __builtin_fmaxf(__builtin_fabsf(ra[i][2]), __builtin_fabsf(ra[i][3]))));
-        Piece<2>::split(ra[i], p);
+        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(ra[i][0])), __builtin_fabsf(ra[i][1]));      // v_max3_f32 with |.| modifiers
+        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(ra[i][2])), __builtin_fabsf(ra[i][3]));
+        if (ABL & 32) {          // measurement only: pretend the activations arrive pre-split (no conversion VALU, same bytes)
+            typedef float v2f_ __attribute__((ext_vector_type(2)));
+            p[0] = __builtin_bit_cast(h4, (v2f_){ra[i][0], ra[i][1]});
+            p[1] = __builtin_bit_cast(h4, (v2f_){ra[i][2], ra[i][3]});
+        } else {
+            Piece<2>::split(ra[i], p);
+        }
         *reinterpret_cast<h4*>(&st[wa[i]]) = p[0];
         *reinterpret_cast<h4*>(&st[PLANE + wa[i]]) = p[1];
     };
@@ -938,7 +949,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
             const int idx = tid + 256 * u;
             const int row = idx / UPR4, c4 = idx % UPR4;
             const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
-            if (m < M && n < N) {
+            if (m < M && n < ((N + 7) & ~7)) {
                 v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
                 if (EPI == EPI_RES || EPI == EPI_MASK) v += rv[u];
                 if (EPI == EPI_MASK) {

@@ -131,7 +131,7 @@ int main(int argc, char** argv)
     constexpr int NV = 12;
     const char* names[NV] = {"fp32 mfma (product kernel)", "fp16x2  64: A fly, B planes", "fp16x2 128: A fly, B planes (product)", "fp16x2 128: 8 waves",
                              "fp16x2 128: product, no global stores", "fp16x2 128: product, no epilogue", "fp16x2 128: no gload, no epilogue", "fp16x2 128: no mfma, no epilogue",
-                             "fp16x2 128 pipelined", "fp16x2  64 pipelined", "fp16x2 128 pipelined, no gload", "fp16x2 128 pipelined, no mfma"};
+                             "fp16x2 128 pipelined", "fp16x2  64 pipelined", "fp16x2 128 pipelined, no gload", "fp16x2 128 pipelined, no split VALU"};
     std::vector<float> t[NV];
     for (int rep = 0; rep < 12; ++rep)
         for (int v = 0; v < NV; ++v) {
@@ -148,7 +148,7 @@ int main(int argc, char** argv)
             case 8: launch_gemm_h2<2>(q2, s); break;
             case 9: launch_gemm_h2<1>(q1, s); break;
             case 10: launch_gemm_h2<2, 1>(q2, s); break;
-            default: launch_gemm_h2<2, 2>(q2, s); }
+            default: launch_gemm_h2<2, 32>(q2, s); }
             CK(hipEventRecord(b, s));
             CK(hipEventSynchronize(b));
             float ms; CK(hipEventElapsedTime(&ms, a, b));
