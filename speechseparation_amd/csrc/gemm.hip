@@ -776,11 +776,21 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + sk)) * zm;
     };
+    // steady state: wave-uniform base advanced by the slab (scalar) + loop-invariant 32-bit byte offsets, so the
+    // loads take the saddr + voffset form and cost no VALU address arithmetic
+    unsigned oab[4], obb[2 * NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oab[i] = oa[i] * 4u;
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) obb[i] = obp[i] * 2u;
+    typedef const char __attribute__((address_space(1)))* gcc;
     auto gload_full = [&](int k0) {
+        const gcc wb_ = (gcc)(Wp + 2 * k0);
+        const gcc xb_ = (gcc)(X + k0);
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) rbp[i] = *(gch8)(Wp + (obp[i] + 2 * k0));
+        for (int i = 0; i < 2 * NT; ++i) rbp[i] = *(gch8)(wb_ + obb[i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + k0));
+        for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(xb_ + oab[i]);
     };
     // LDS offsets (halves) of this thread's staging units; 16-byte unit kq of row r sits at unit kq ^ ((r >> 2) & 3)
     int wa[4], wb[2 * NT];
