@@ -84,7 +84,7 @@ struct bsrnn_ctx {
     // workspace (grow-only)
     size_t cap_rows = 0;
     float* d_ws = nullptr;
-    float *Xf, *Yf, *A1, *A2, *P, *Z0, *Z1, *HB0, *HB1, *H1, *frames;
+    float *Xf, *Yf, *A1, *A2, *P, *Z0, *Z1, *HB0, *HB1, *H1;
     size_t tap_rows = 0;
     float* d_tap = nullptr;
 
@@ -257,8 +257,8 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
     if (c->d_ws) { HIP_TRY(hipFree(c->d_ws)); c->d_ws = nullptr; c->cap_rows = 0; }
     const size_t KH = (size_t)c->K * HID;
     auto seg = [](size_t n) { return (n + 63) & ~size_t(63); };
-    const size_t sizes[11] = {seg(rows * c->LDP), seg(rows * c->LDP), seg(rows * c->LDA), seg(rows * c->LDA), seg(rows * c->LDP),
-                              seg(rows * KH), seg(rows * KH), seg(rows * KH * 2), seg(rows * KH * 2), seg(rows * KH), seg(rows * NFFT)};
+    const size_t sizes[10] = {seg(rows * c->LDP), seg(rows * c->LDP), seg(rows * c->LDA), seg(rows * c->LDA), seg(rows * c->LDP),
+                              seg(rows * KH), seg(rows * KH), seg(rows * KH * 2), seg(rows * KH * 2), seg(rows * KH)};
     size_t total = 0;
     for (size_t s : sizes) total += s;
     HIP_TRY(hipMalloc((void**)&c->d_ws, total * sizeof(float)));
@@ -266,8 +266,8 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
     // never written afterwards: they must be finite, so the whole workspace starts at zero
     HIP_TRY(hipMemset(c->d_ws, 0, total * sizeof(float)));
     float* p = c->d_ws;
-    float** dst[11] = {&c->Xf, &c->Yf, &c->A1, &c->A2, &c->P, &c->Z0, &c->Z1, &c->HB0, &c->HB1, &c->H1, &c->frames};
-    for (int i = 0; i < 11; ++i) { *dst[i] = p; p += sizes[i]; }
+    float** dst[10] = {&c->Xf, &c->Yf, &c->A1, &c->A2, &c->P, &c->Z0, &c->Z1, &c->HB0, &c->HB1, &c->H1};
+    for (int i = 0; i < 10; ++i) { *dst[i] = p; p += sizes[i]; }
     c->cap_rows = rows;
     return 0;
 }
@@ -314,7 +314,7 @@ struct Part {
     int C, T;                       // rows and frames of this part
     hipStream_t s;
     const float* Xf; float* Yf; float* tap;              // [C*T][LDP], band-padded spectrum layout
-    float *A1, *A2, *P, *Z0, *Z1, *HB0, *HB1, *H1, *frames;
+    float *A1, *A2, *P, *Z0, *Z1, *HB0, *HB1, *H1;
     const float* state_in; float* state_out;             // [4][2][C_total*K][64] slabs already offset to this part's first row
     size_t state_slab;                                   // floats between the two Time blocks' slabs (uses C_total)
     const float* wave; float* wave_out; int64_t n;       // only for the fused sandwich
@@ -330,7 +330,6 @@ Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s)
     p.A1 = c->A1 + m0 * c->LDA; p.A2 = c->A2 + m0 * c->LDA; p.P = c->P + m0 * c->LDP;
     p.Z0 = c->Z0 + m0 * KH; p.Z1 = c->Z1 + m0 * KH; p.H1 = c->H1 + m0 * KH;
     p.HB0 = c->HB0 + m0 * KH * 2; p.HB1 = c->HB1 + m0 * KH * 2;
-    p.frames = c->frames + m0 * NFFT;
     return p;
 }
 
@@ -393,8 +392,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     case MS_ISTFT:
         if (p.wave_out) {
             StageScope sc(c, ST_ISTFT, s);
-            launch_istft_frames(c->tb, p.Yf, p.frames, M, s);
-            launch_istft_ola(c->tb, p.frames, p.wave_out, p.C, p.T, s);
+            launch_istft(c->tb, p.Yf, p.wave_out, p.C, p.T, s);
         }
         break;
     }
@@ -938,8 +936,7 @@ int bsrnn_istft(bsrnn_ctx* c, const float* y, float* wave_out, int32_t R, int32_
     { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, y, c->Yf, R, T, s); }
     {
         StageScope sc(c, ST_ISTFT, s);
-        launch_istft_frames(c->tb, c->Yf, c->frames, R * T, s);
-        launch_istft_ola(c->tb, c->frames, wave_out, R, T, s);
+        launch_istft(c->tb, c->Yf, wave_out, R, T, s);
     }
     HIP_TRY(hipGetLastError());
     return 0;

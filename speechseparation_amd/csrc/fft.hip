@@ -112,20 +112,23 @@ __device__ __forceinline__ void rfft_split_store(const float2* Z, const SplitCtx
 
 // Z[k] = E[k] + i O[k] for the inverse; imaginary parts of DC / Nyquist are ignored like c2r does.
 // `lin` = true: Y is a plain interleaved [2050] row (LDS copy), else columns come from sc.
+struct MergeRegs { float2 xk[4], xc[4]; };
 template <bool LIN>
-__device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const SplitCtx& sc, float2* z, int tid)
+__device__ __forceinline__ void irfft_load(const float* __restrict__ Y, const SplitCtx& sc, MergeRegs& r, int tid)
 {
-    float2 xk[4], xc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                                     // all loads first
-        const int k = tid + 256 * i;
-        xk[i] = *reinterpret_cast<const float2*>(Y + (LIN ? 2 * k : sc.col[i]));
-        xc[i] = *reinterpret_cast<const float2*>(Y + (LIN ? 2 * (1024 - k) : sc.colr[i]));
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = tid + 256 * i;
-        float2 a = xk[i], b = xc[i];
+        r.xk[i] = *reinterpret_cast<const float2*>(Y + (LIN ? 2 * k : sc.col[i]));
+        r.xc[i] = *reinterpret_cast<const float2*>(Y + (LIN ? 2 * (1024 - k) : sc.colr[i]));
+    }
+}
+__device__ __forceinline__ void irfft_store(const MergeRegs& r, const SplitCtx& sc, float2* z, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        float2 a = r.xk[i], b = r.xc[i];
         if (k == 0) { a.y = 0.f; b.y = 0.f; }
         b = cconj(b);
         const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
@@ -133,6 +136,13 @@ __device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const S
         const float2 o = cmul(dd, cconj(sc.tw[i]));
         z[k] = make_float2(e.x - o.y, e.y + o.x);                     // e + i*o
     }
+}
+template <bool LIN>
+__device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const SplitCtx& sc, float2* z, int tid)
+{
+    MergeRegs r;
+    irfft_load<LIN>(Y, sc, r, tid);                                   // all loads first
+    irfft_store(r, sc, z, tid);
 }
 
 // ------------------------------------------------------------------------------ offline STFT
@@ -170,55 +180,61 @@ void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_
 }
 
 // ------------------------------------------------------------------------------ offline iSTFT
-__global__ __launch_bounds__(256) void istft_frames_kernel(FftTables tb, const float* __restrict__ Y, float* __restrict__ frames)
+// One workgroup produces ICH consecutive output hops of one row: output hop b = first half of synthesis frame
+// b + 1 + second half of frame b, divided by the window envelope (torch.istft).  The workgroup walks frames
+// b0 .. b0 + ICH, keeps the windowed second half of the previous frame in registers (the thread that owns complex
+// samples c, c + 256 of a frame's first half also owns c + 512, c + 768 of the second half) and recomputes one
+// frame per chunk - no [M][2048] frame buffer in HBM and no separate overlap-add launch (was 132 MB + 15 us).
+// The spectrum of frame t + 1 is requested before the FFT passes of frame t.
+constexpr int ICH = 6;
+__global__ __launch_bounds__(256) void istft_fused_kernel(FftTables tb, const float* __restrict__ Y, float* __restrict__ out, int T)
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<true>(tb.tw1024, tid);
     const SplitCtx spl = load_split(tb, tid, true);
-    const size_t m = blockIdx.x;
-    irfft_merge<false>(Y + m * tb.ld, spl, z0, tid);
-    __syncthreads();
-    const float2* z = fft1024<true>(z0, z1, twd, tid);
-    float* dst = frames + m * NFFT;
+    const int r = blockIdx.y;
+    const int b0 = blockIdx.x * ICH;
+    const int b1 = (b0 + ICH < T - 1) ? b0 + ICH : T - 1;          // output hops [b0, b1) <- frames b0 .. b1
+    const size_t len = (size_t)(T - 1) * HOPS;
     const float sc = 1.0f / 1024.0f;
-    for (int c = tid; c < 1024; c += 256) {
-        const float2 v = z[c];
-        *reinterpret_cast<float2*>(dst + 2 * c) =
-            make_float2(v.x * sc * tb.hann[2 * c], v.y * sc * tb.hann[2 * c + 1]);
+    float2 wlo[2], whi[2], env[2], carry[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 256 * k;
+        wlo[k] = make_float2(tb.hann[2 * c] * sc, tb.hann[2 * c + 1] * sc);
+        whi[k] = make_float2(tb.hann[2 * c + HOPS] * sc, tb.hann[2 * c + 1 + HOPS] * sc);
+        env[k] = make_float2(tb.inv_env[2 * c], tb.inv_env[2 * c + 1]);
+        carry[k] = make_float2(0.f, 0.f);
+    }
+    const float* Yr = Y + (size_t)r * T * tb.ld;
+    MergeRegs mr;
+    irfft_load<false>(Yr + (size_t)b0 * tb.ld, spl, mr, tid);
+    for (int t = b0; t <= b1; ++t) {
+        irfft_store(mr, spl, z0, tid);
+        __syncthreads();
+        if (t < b1) irfft_load<false>(Yr + (size_t)(t + 1) * tb.ld, spl, mr, tid);
+        const float2* z = fft1024<true>(z0, z1, twd, tid);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = tid + 256 * k;
+            const float2 a = z[c], b = z[c + 512];
+            if (t > b0) {
+                // same operation order as the two-pass version: (frame * 1/1024 * window) summed, then / envelope
+                const float2 v = make_float2((a.x * wlo[k].x + carry[k].x) * env[k].x, (a.y * wlo[k].y + carry[k].y) * env[k].y);
+                *reinterpret_cast<float2*>(out + (size_t)r * len + (size_t)(t - 1) * HOPS + 2 * c) = v;
+            }
+            carry[k] = make_float2(b.x * whi[k].x, b.y * whi[k].y);
+        }
+        __syncthreads();                          // z (= z1) is overwritten by the next frame's first pass
     }
 }
 
-__global__ __launch_bounds__(256) void istft_ola_kernel(FftTables tb, const float* __restrict__ frames, float* __restrict__ out, int T)
-{
-    // out[r][s], s in [0, (T-1)*1024): padded position p = s + 1024 is covered by frame t1 = p/1024
-    // at offset off and by frame t1-1 at offset off + 1024
-    const int r = blockIdx.y;
-    const int64_t len = (int64_t)(T - 1) * HOPS;
-    const int64_t s4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (s4 >= len) return;
-    const int64_t p = s4 + HOPS;
-    const int t1 = (int)(p / HOPS);
-    const int off = (int)(p % HOPS);
-    const float* f1 = frames + ((size_t)r * T + t1) * NFFT + off;
-    const float* f0 = frames + ((size_t)r * T + t1 - 1) * NFFT + off + HOPS;
-    const float4 a = *reinterpret_cast<const float4*>(f1);
-    const float4 b = *reinterpret_cast<const float4*>(f0);
-    const float4 e = *reinterpret_cast<const float4*>(tb.inv_env + off);
-    *reinterpret_cast<float4*>(out + (size_t)r * len + s4) =
-        make_float4((a.x + b.x) * e.x, (a.y + b.y) * e.y, (a.z + b.z) * e.z, (a.w + b.w) * e.w);
-}
-
-void launch_istft_frames(const FftTables& tb, const float* Y, float* frames, int M, hipStream_t s)
-{
-    hipLaunchKernelGGL(istft_frames_kernel, dim3(M), dim3(256), 0, s, tb, Y, frames);
-}
-void launch_istft_ola(const FftTables& tb, const float* frames, float* out, int R, int T, hipStream_t s)
+void launch_istft(const FftTables& tb, const float* Y, float* out, int R, int T, hipStream_t s)
 {
     if (T < 2) return;
-    const int64_t len = (int64_t)(T - 1) * HOPS;
-    dim3 grid((unsigned)((len / 4 + 255) / 256), R);
-    hipLaunchKernelGGL(istft_ola_kernel, grid, dim3(256), 0, s, tb, frames, out, T);
+    dim3 grid((unsigned)((T - 1 + ICH - 1) / ICH), R);
+    hipLaunchKernelGGL(istft_fused_kernel, grid, dim3(256), 0, s, tb, Y, out, T);
 }
 
 // ------------------------------------------------------------------------------ [C][2050][T] <-> [C*T][ld]

@@ -93,9 +93,8 @@ struct FftTables {           // device tables, built once per context (double pr
 };
 // wave [R][n] -> X frame-major [R*T][ld] (re/im interleaved, band-padded columns), reflect padding, Hann.
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s);
-// Y frame-major [R*T][ld] -> windowed synthesis frames [R*T][2048] -> wave_out [R][(T-1)*1024]
-void launch_istft_frames(const FftTables& tb, const float* Y, float* frames, int M, hipStream_t s);
-void launch_istft_ola(const FftTables& tb, const float* frames, float* out, int R, int T, hipStream_t s);
+// Y frame-major [R*T][ld] -> wave_out [R][(T-1)*1024]: inverse real FFT, synthesis window, overlap-add / envelope, fused
+void launch_istft(const FftTables& tb, const float* Y, float* out, int R, int T, hipStream_t s);
 // [C][2050][T] (reference layout) <-> [C*T][ld] (band-padded)
 void launch_to_frame_major(const FftTables& tb, const float* x, float* xf, int C, int T, hipStream_t s);
 void launch_from_frame_major(const FftTables& tb, const float* yf, float* y, int C, int T, hipStream_t s);
