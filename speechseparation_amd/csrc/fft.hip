@@ -146,6 +146,10 @@ __device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const S
 }
 
 // ------------------------------------------------------------------------------ offline STFT
+// One workgroup transforms SCH consecutive frames of one row.  Frames overlap by half: the thread that owns complex
+// samples c + 512, c + 768 of frame t owns c, c + 256 of frame t + 1, so only the new half is loaded per frame
+// (requested before the FFT passes of the current frame) and the raw samples stay in registers.
+constexpr int SCH = 6;
 __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __restrict__ wave, float* __restrict__ X,
                                                    int64_t n, int T)
 {
@@ -153,30 +157,44 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<false>(tb.tw1024, tid);
     const SplitCtx spl = load_split(tb, tid, false);
-    const int m = blockIdx.x;                  // r*T + t
-    const int r = m / T, t = m % T;
+    const int r = blockIdx.y;
+    const int t0 = blockIdx.x * SCH;
+    const int t1 = (t0 + SCH < T) ? t0 + SCH : T;
     const float* src = wave + (size_t)r * n;
-    // padded frame sample i (0..2047) is original index t*1024 + i - 1024, reflected at both ends
-    for (int c = tid; c < 1024; c += 256) {
+    float2 win[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) win[k] = make_float2(tb.hann[2 * (tid + 256 * k)], tb.hann[2 * (tid + 256 * k) + 1]);
+    // padded frame sample i (0..2047) of frame t is original index t*1024 + i - 1024, reflected at both ends
+    auto sample2 = [&](int t, int c) {
         float v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int i = 2 * c + e;
-            int64_t idx = (int64_t)t * HOPS + i - NFFT / 2;
+            int64_t idx = (int64_t)t * HOPS + 2 * c + e - NFFT / 2;
             if (idx < 0) idx = -idx;
             if (idx >= n) idx = 2 * (n - 1) - idx;
-            v[e] = src[idx] * tb.hann[i];
+            v[e] = src[idx];
         }
-        z0[c] = make_float2(v[0], v[1]);
+        return make_float2(v[0], v[1]);
+    };
+    float2 raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[k] = sample2(t0, tid + 256 * k);
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z0[tid + 256 * k] = make_float2(raw[k].x * win[k].x, raw[k].y * win[k].y);
+        __syncthreads();
+        raw[0] = raw[2]; raw[1] = raw[3];
+        if (t + 1 < t1) { raw[2] = sample2(t + 1, tid + 512); raw[3] = sample2(t + 1, tid + 768); }
+        const float2* Z = fft1024<false>(z0, z1, twd, tid);
+        rfft_split_store(Z, spl, X + ((size_t)r * T + t) * tb.ld, tid);
+        __syncthreads();                          // Z (= z1) is overwritten by the next frame's first pass
     }
-    __syncthreads();
-    const float2* Z = fft1024<false>(z0, z1, twd, tid);
-    rfft_split_store(Z, spl, X + (size_t)m * tb.ld, tid);
 }
 
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s)
 {
-    hipLaunchKernelGGL(stft_kernel, dim3(R * T), dim3(256), 0, s, tb, wave, X, n, T);
+    dim3 grid((unsigned)((T + SCH - 1) / SCH), R);
+    hipLaunchKernelGGL(stft_kernel, grid, dim3(256), 0, s, tb, wave, X, n, T);
 }
 
 // ------------------------------------------------------------------------------ offline iSTFT
