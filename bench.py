@@ -74,18 +74,18 @@ def host_cores():
 
 
 # The ten grouped-GEMM launches of the two bracketed stages, by kernel instance (template arguments as rocprofv3
-# prints them) -> launches per step.  Split kernels: <epilogue, pieces, tile (1 = 128x64, 2 = 128x128), ...>.
+# prints them) -> launches per step.  gemm_h2_kernel<epilogue, tile (1 = 128x64, 2 = 128x128), ablation>;
+# gemm_split_kernel<epilogue, pieces, tile, ...>.
 GEMM_LAUNCH_MIX = {
     "f32": (("gemm_f32_kernel<1,", 8), ("gemm_f32_kernel<0,", 1), ("gemm_f32_kernel<3,", 1)),
-    "fp16x2": (("gemm_split_kernel<1, 2, 2,", 6), ("gemm_split_kernel<1, 2, 1,", 2), ("gemm_split_kernel<0, 2, 1,", 1),
-               ("gemm_split_kernel<3, 2, 2,", 1)),
+    "fp16x2": (("gemm_h2_kernel<1, 2,", 6), ("gemm_h2_kernel<1, 1,", 2), ("gemm_h2_kernel<0, 1,", 1), ("gemm_h2_kernel<3, 2,", 1)),
     "bf16x3": (("gemm_split_kernel<1, 3, 2,", 6), ("gemm_split_kernel<1, 3, 1,", 2), ("gemm_split_kernel<0, 3, 1,", 1),
                ("gemm_split_kernel<3, 3, 2,", 1)),
 }
 # matrix-pipe roofline of the grouped GEMM per mode: (kernel, peak in algorithmic TFLOP/s, how it is derived)
 GEMM_ROOF = {
     "f32": ("gemm_f32_kernel", 157.3, "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32, exact fp32)"),
-    "fp16x2": ("gemm_split_kernel<fp16x2>", 2500.0 / 3, "f16 MFMA dense peak 2500 TFLOP/s / 3 MFMA terms per fp32-accurate product "
+    "fp16x2": ("gemm_h2_kernel", 2500.0 / 3, "f16 MFMA dense peak 2500 TFLOP/s / 3 MFMA terms per fp32-accurate product "
                "(a1b1 + a1b2 + a2b1, fp32 accumulate)"),
     "bf16x3": ("gemm_split_kernel<bf16x3>", 2500.0 / 6, "bf16 MFMA dense peak 2500 TFLOP/s / 6 MFMA terms per fp32-accurate product"),
 }
