@@ -1,0 +1,25 @@
+"""The alternate compute modes (BSRNN_GEMM / BSRNN_LSTM, read once per process) are held to the same parity and
+precision tests as the default: each mode runs the reference-fixture and float64-precision tests in a child
+process of its own."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("gemm,lstm", [("f32", "f32"), ("bf16x3", "fp16x2"), ("fp16x2", "f32")])
+def test_parity_in_mode(gemm, lstm):
+    env = dict(os.environ, BSRNN_GEMM=gemm, BSRNN_LSTM=lstm)
+    sel = "test_compute_mode_is_reported or test_forward_mask_vs_reference or test_precision_is_at_fp32_rounding_level " \
+          "or test_forward_recurrent_and_chunks_vs_reference or test_stft_istft_separate_vs_reference"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-s",
+                        "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "'gemm': '%s'" % gemm in r.stdout and "'lstm': '%s'" % lstm in r.stdout
