@@ -79,6 +79,7 @@ def host_cores():
 GEMM_LAUNCH_MIX = {
     "f32": (("gemm_f32_kernel<1,", 8), ("gemm_f32_kernel<0,", 1), ("gemm_f32_kernel<3,", 1)),
     "fp16x2": (("gemm_h2_kernel<1, 2,", 6), ("gemm_h2_kernel<1, 1,", 2), ("gemm_h2_kernel<0, 1,", 1), ("gemm_h2_kernel<3, 2,", 1)),
+    "fp16": (("gemm_h2_kernel<1, 2, 0, 1>", 6), ("gemm_h2_kernel<1, 1, 0, 1>", 2), ("gemm_h2_kernel<0, 1, 0, 1>", 1), ("gemm_h2_kernel<3, 2, 0, 1>", 1)),
     "bf16x3": (("gemm_split_kernel<1, 3, 2,", 6), ("gemm_split_kernel<1, 3, 1,", 2), ("gemm_split_kernel<0, 3, 1,", 1),
                ("gemm_split_kernel<3, 3, 2,", 1)),
 }
@@ -87,6 +88,8 @@ GEMM_ROOF = {
     "f32": ("gemm_f32_kernel", 157.3, "fp32 MFMA dense peak (v_mfma_f32_32x32x2_f32, exact fp32)"),
     "fp16x2": ("gemm_h2_kernel", 2500.0 / 3, "f16 MFMA dense peak 2500 TFLOP/s / 3 MFMA terms per fp32-accurate product "
                "(a1b1 + a1b2 + a2b1, fp32 accumulate)"),
+    "fp16": ("gemm_h2_kernel<fp16, 1 term>", 2500.0, "f16 MFMA dense peak; REDUCED PRECISION (plain fp16 operands, ~5e-4 relative per product): "
+             "not the fp32-accurate default"),
     "bf16x3": ("gemm_split_kernel<bf16x3>", 2500.0 / 6, "bf16 MFMA dense peak 2500 TFLOP/s / 6 MFMA terms per fp32-accurate product"),
 }
 
@@ -243,7 +246,7 @@ def main():
             "metric": "separated row-frames/sec, batch64 8s@16kHz",
             "value": round(value, 1), "unit": "row-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if cmode["gemm"] != "fp16" else "f16 (fp32 accumulate)", "data": "synthetic",
             "config": {"workload": "offline separate (STFT->BSRNN.forward->iSTFT), %d rows/GPU x %d samples @16 kHz (T=%d), K=12 bands, fp32"
                                    % (args.rows, args.samples, T),
                        "rows_per_gpu": args.rows, "global_rows": args.rows * world, "frames": T, "parallelism": "dp%d (row shards, no in-path collective)" % world},

@@ -47,7 +47,9 @@ const char* bsrnn_last_error(void);
  * carries the products: "f32" = v_mfma_f32_*_f32 (exact fp32 fma chains), "fp16x2" / "bf16x3" = fp32 operands
  * split into 2 fp16 / 3 bf16 pieces and multiplied on the 16-bit matrix cores with fp32 accumulation
  * (error at the level of fp32 rounding noise).  Selected once per process by the environment
- * variables BSRNN_GEMM (f32 | fp16x2 | bf16x3) and BSRNN_LSTM (f32 | fp16x2); default fp16x2 for both.
+ * variables BSRNN_GEMM (f32 | fp16x2 | bf16x3 | fp16) and BSRNN_LSTM (f32 | fp16x2); default fp16x2 for both.
+ * BSRNN_GEMM=fp16 is the one REDUCED-precision mode (plain fp16 operands in the Linear layers, one MFMA term,
+ * fp32 accumulation: ~1e-3 of the output range); it exists for the "16-bit compute" benchmark configuration.
  * Range: the fp16x2 mode represents operands up to |a| = 65504 (spectra of audio in [-1, 1] stay below 1024).
  * A larger activation saturates; the kernels notice, and the NEXT call on the context (or bsrnn_sync) fails
  * with BSRNN_ERANGE instead of returning a silently different result.  Rescale the input or use "f32". */

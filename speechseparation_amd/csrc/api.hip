@@ -440,7 +440,7 @@ const char* bsrnn_compute_mode(void)
 {
     static char buf[64];
     const int g = gemm_mode(), l = lstm_mode();
-    snprintf(buf, sizeof buf, "gemm=%s lstm=%s", g == GEMM_F32 ? "f32" : (g == GEMM_FP16X2 ? "fp16x2" : "bf16x3"),
+    snprintf(buf, sizeof buf, "gemm=%s lstm=%s", g == GEMM_F32 ? "f32" : (g == GEMM_FP16X2 ? "fp16x2" : (g == GEMM_FP16 ? "fp16" : "bf16x3")),
              l == LSTM_F32 ? "f32" : "fp16x2");
     return buf;
 }
@@ -600,7 +600,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     auto put_planes = [&](const std::vector<float>& wp, int N, int Kp) -> size_t {
         if (gmode == GEMM_F32 || wp.empty()) return 0;
         std::vector<uint16_t> pl;
-        if (gmode == GEMM_FP16X2) {          // slab-interleaved pieces, rows padded to a multiple of 32 (gemm_h2_kernel)
+        if (gmode == GEMM_FP16X2 || gmode == GEMM_FP16) {          // slab-interleaved pieces, rows padded to a multiple of 32 (gemm_h2_kernel)
             const int K32 = (Kp + 31) & ~31, wrow = h2_row_stride(K32);
             pl.assign((size_t)N * wrow + 1, 0);
             pack_h2_slabs_host(wp.data(), N, Kp, Kp, K32, wrow, pl.data());

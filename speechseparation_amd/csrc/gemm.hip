@@ -703,9 +703,12 @@ __device__ __forceinline__ void sched_slice()
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          //   one global load
 }
 
-template <int EPI, int NT, int ABL = 0>
-__global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLaunch g)
+// TERMS = 3: fp16x2 (hi + two correction terms).  TERMS = 1: plain fp16 operands, one MFMA term (the "16-bit compute"
+// configuration of BASELINE.json: ~5e-4 relative error per product) - only the first piece of each operand is staged.
+template <int EPI, int NT, int ABL = 0, int TERMS = 3>
+__global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h2_kernel(GemmLaunch g)
 {
+    constexpr int NPL = TERMS == 1 ? 1 : 2;         // pieces staged per operand
     typedef _Float16 hT;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -714,10 +717,10 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     typedef const v4f __attribute__((address_space(1)))* gcf4;
     constexpr int BN = 64 * NT;
     constexpr int PLANE = (BM + BN) * 32;           // halves per piece and stage: A rows then B rows, 64-byte rows
-    constexpr int STAGE = 2 * PLANE;
+    constexpr int STAGE = NPL * PLANE;
     constexpr int ES = BN + 4;
-    __shared__ __attribute__((aligned(16))) hT smemh[2 * STAGE];
-    static_assert(2 * STAGE * 2 >= 64 * ES * 4, "epilogue staging must fit");
+    constexpr int SMEM_H = 2 * STAGE * 2 >= 64 * ES * 4 ? 2 * STAGE : 64 * ES * 2;      // two stages, or the epilogue staging tile if larger
+    __shared__ __attribute__((aligned(16))) hT smemh[SMEM_H];
 
     const int m_tiles = (g.M + BM - 1) / BM;
     const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
@@ -755,16 +758,19 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     // weights: [N][K32 / 32][2 pieces][32] fp16 (split_host.h, pack_h2_slabs_host): the two pieces of a slab of a row
     // are one 128-byte line; rows are zero-padded to K32, so the weight side needs no tail masking
     const unsigned wrow = (unsigned)job.wrow;
-    unsigned oa[4], obp[2 * NT];
+    // weight staging: 8 units (both pieces) of a row's slab per 8 threads, or the 4 units of the first piece per 4 threads
+    constexpr int BPASS = TERMS == 1 ? NT : 2 * NT, BROWS = TERMS == 1 ? 64 : 32;
+    const int b_row = TERMS == 1 ? tid >> 2 : tid >> 3, b_u = TERMS == 1 ? tid & 3 : tid & 7;
+    unsigned oa[4], obp[BPASS];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { int row = m0 + s_row + 32 * i; row = row < M ? row : M - 1; oa[i] = (unsigned)row * (unsigned)g.ldx + 4 * s_k4; }
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) { int row = n0 + s_row + 32 * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * wrow + 8 * s_k4; }
+    for (int i = 0; i < BPASS; ++i) { int row = n0 + b_row + BROWS * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * wrow + 8 * b_u; }
     v4f ra[4];
-    h8 rbp[2 * NT];
+    h8 rbp[BPASS];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) rbp[i] = *(gch8)(Wp + (obp[i] + 2 * k0));
+        for (int i = 0; i < BPASS; ++i) rbp[i] = *(gch8)(Wp + (obp[i] + 2 * k0));
         if (k0 + 32 <= K) {          // plain loads: no arithmetic on the registers until they are written to LDS
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(X + (oa[i] + k0));
@@ -778,26 +784,26 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     };
     // steady state: wave-uniform base advanced by the slab (scalar) + loop-invariant 32-bit byte offsets, so the
     // loads take the saddr + voffset form and cost no VALU address arithmetic
-    unsigned oab[4], obb[2 * NT];
+    unsigned oab[4], obb[BPASS];
 #pragma unroll
     for (int i = 0; i < 4; ++i) oab[i] = oa[i] * 4u;
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) obb[i] = obp[i] * 2u;
+    for (int i = 0; i < BPASS; ++i) obb[i] = obp[i] * 2u;
     typedef const char __attribute__((address_space(1)))* gcc;
     auto gload_full = [&](int k0) {
         const gcc wb_ = (gcc)(Wp + 2 * k0);
         const gcc xb_ = (gcc)(X + k0);
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) rbp[i] = *(gch8)(wb_ + obb[i]);
+        for (int i = 0; i < BPASS; ++i) rbp[i] = *(gch8)(wb_ + obb[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *(gcf4)(xb_ + oab[i]);
     };
     // LDS offsets (halves) of this thread's staging units; 16-byte unit kq of row r sits at unit kq ^ ((r >> 2) & 3)
-    int wa[4], wb[2 * NT];
+    int wa[4], wb[BPASS];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int r = s_row + 32 * i; wa[i] = r * 32 + (((s_k4 >> 1) ^ ((r >> 2) & 3)) * 8) + (s_k4 & 1) * 4; }
 #pragma unroll
-    for (int i = 0; i < 2 * NT; ++i) { const int r = BM + s_row + 32 * i; wb[i] = (s_k4 >> 2) * PLANE + r * 32 + (((s_k4 & 3) ^ ((r >> 2) & 3)) * 8); }
+    for (int i = 0; i < BPASS; ++i) { const int r = BM + b_row + BROWS * i; wb[i] = (b_u >> 2) * PLANE + r * 32 + (((b_u & 3) ^ ((r >> 2) & 3)) * 8); }
     float amax = 0.f;                             // largest |activation| staged by this thread (range guard)
     auto put_a = [&](hT* st, int i) {
         h4 p[2];
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
             Piece<2>::split(ra[i], p);
         }
         *reinterpret_cast<h4*>(&st[wa[i]]) = p[0];
-        *reinterpret_cast<h4*>(&st[PLANE + wa[i]]) = p[1];
+        if (TERMS != 1) *reinterpret_cast<h4*>(&st[PLANE + wa[i]]) = p[1];
     };
     auto put_b = [&](hT* st, int i) {
         *reinterpret_cast<h8*>(&st[wb[i]]) = rbp[i];
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
 #pragma unroll
         for (int i = 0; i < 4; ++i) put_a(smemh, i);
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) put_b(smemh, i);
+        for (int i = 0; i < BPASS; ++i) put_b(smemh, i);
         if (K > 32) gload(32);
     }
     __syncthreads();
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
             for (int ks = 0; ks < 2; ++ks) {
                 h8 b[NT][2], a[2][2];
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) b[j][pl] = *reinterpret_cast<const h8*>(&cur[pl * PLANE + fb + 32 * j * 32 + fu[ks]]);
 #pragma unroll
@@ -862,14 +868,16 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
                         if (!FAST && j > 0 && !live[j]) continue;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j][1], 0, 0, 0);
-                            acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j][1], 0, 0, 0);
+                            if (TERMS != 1) {
+                                acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], acc[i][j][1], 0, 0, 0);
+                                acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], acc[i][j][1], 0, 0, 0);
+                            }
                             acc[i][j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j][0], 0, 0, 0);
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) { acc[i][0][0][ks] += (float)a[i][0][0] + (float)a[i][1][1]; acc[i][NT - 1][1][ks] += (float)b[NT - 1][0][0] + (float)b[NT - 1][1][1]; }
+                    for (int i = 0; i < 2; ++i) { acc[i][0][0][ks] += (float)a[i][0][0] + (float)a[i][NPL - 1][1]; acc[i][NT - 1][1][ks] += (float)b[NT - 1][0][0] + (float)b[NT - 1][NPL - 1][1]; }
                 }
                 // the next slab's staging rides behind this half's MFMAs: A rows after ks = 0, B rows and the
                 // global loads of the slab after that behind ks = 1
@@ -879,7 +887,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
                         for (int i = 0; i < 4; ++i) put_a(nxt, i);
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 2 * NT; ++i) put_b(nxt, i);
+                        for (int i = 0; i < BPASS; ++i) put_b(nxt, i);
                     }
                 }
                 if (ks == 1 && !(ABL & 1)) {
@@ -899,7 +907,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
 #pragma unroll
             for (int i = 0; i < 4; ++i) put_a(nxt, i);
 #pragma unroll
-            for (int i = 0; i < 2 * NT; ++i) put_b(nxt, i);
+            for (int i = 0; i < BPASS; ++i) put_b(nxt, i);
             if (!(ABL & 1) && k0 + 64 < K) gload(k0 + 64);
         }
         __syncthreads();
@@ -946,7 +954,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        float v = (acc[i][j][0][reg] + (1.f / 2048.f) * acc[i][j][1][reg]) + bias[j];
+                        float v = (TERMS == 1 ? acc[i][j][0][reg] : acc[i][j][0][reg] + (1.f / 2048.f) * acc[i][j][1][reg]) + bias[j];
                         if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
                         if (!in) v = 0.f;
                         sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + col] = v;
@@ -972,7 +980,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2_kernel(GemmLau
     }
 }
 
-template <int NT, int ABL = 0>
+template <int NT, int ABL = 0, int TERMS = 3>
 static void launch_gemm_h2(const GemmLaunch& g_in, hipStream_t stream)
 {
     GemmLaunch g = g_in;
@@ -981,10 +989,10 @@ static void launch_gemm_h2(const GemmLaunch& g_in, hipStream_t stream)
     const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
     dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(256);
     switch (g.epilogue) {
-    case EPI_LINEAR: hipLaunchKernelGGL((gemm_h2_kernel<EPI_LINEAR, NT, ABL>), grid, block, 0, stream, g); break;
-    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_h2_kernel<EPI_LEAKY, NT, ABL>), grid, block, 0, stream, g); break;
-    case EPI_RES:    hipLaunchKernelGGL((gemm_h2_kernel<EPI_RES, NT, ABL>), grid, block, 0, stream, g); break;
-    default:         hipLaunchKernelGGL((gemm_h2_kernel<EPI_MASK, NT, ABL>), grid, block, 0, stream, g); break;
+    case EPI_LINEAR: hipLaunchKernelGGL((gemm_h2_kernel<EPI_LINEAR, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
+    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_h2_kernel<EPI_LEAKY, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
+    case EPI_RES:    hipLaunchKernelGGL((gemm_h2_kernel<EPI_RES, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
+    default:         hipLaunchKernelGGL((gemm_h2_kernel<EPI_MASK, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
     }
 }
 
@@ -1012,7 +1020,8 @@ int gemm_mode()
         if (!e || !*e || !strcmp(e, "fp16x2")) return (int)GEMM_FP16X2;
         if (!strcmp(e, "f32")) return (int)GEMM_F32;
         if (!strcmp(e, "bf16x3")) return (int)GEMM_BF16X3;
-        fprintf(stderr, "bsrnn: unknown BSRNN_GEMM='%s' (f32 | fp16x2 | bf16x3), using fp16x2\n", e);
+        if (!strcmp(e, "fp16")) return (int)GEMM_FP16;
+        fprintf(stderr, "bsrnn: unknown BSRNN_GEMM='%s' (f32 | fp16x2 | bf16x3 | fp16), using fp16x2\n", e);
         return (int)GEMM_FP16X2;
     }();
     return mode;
@@ -1025,6 +1034,10 @@ void launch_gemm(const GemmLaunch& g, hipStream_t stream)
     case GEMM_FP16X2:
         if (g.tile_n == 128) launch_gemm_h2<2>(g, stream);
         else launch_gemm_h2<1>(g, stream);
+        return;
+    case GEMM_FP16:
+        if (g.tile_n == 128) launch_gemm_h2<2, 0, 1>(g, stream);
+        else launch_gemm_h2<1, 0, 1>(g, stream);
         return;
     case GEMM_BF16X3:
         if (g.tile_n == 128) launch_gemm_split<3, 2, 0, 1, 0, 2>(g, stream);

@@ -54,9 +54,10 @@ struct GemmLaunch {
     int* range_flag;                   // fp16x2: set to 1 when an operand exceeded the fp16 range (may be null)
 };
 void launch_gemm(const GemmLaunch& g, hipStream_t stream);
-// How the Linear layers are evaluated (environment BSRNN_GEMM = f32 | fp16x2 | bf16x3, read once per process).
-// The value is the number of 16-bit planes GemmJob::Wp must hold (0: none).
-enum GemmMode { GEMM_F32 = 0, GEMM_FP16X2 = 2, GEMM_BF16X3 = 3 };
+// How the Linear layers are evaluated (environment BSRNN_GEMM = f32 | fp16x2 | bf16x3 | fp16, read once per process).
+// fp16 = plain 16-bit operands, one MFMA term, fp32 accumulate (the reduced-precision configuration, not the default).
+// f32: no 16-bit weights; fp16x2 / fp16: slab-interleaved fp16 pieces; bf16x3: three bf16 planes.
+enum GemmMode { GEMM_F32 = 0, GEMM_FP16 = 1, GEMM_FP16X2 = 2, GEMM_BF16X3 = 3 };
 int gemm_mode();
 constexpr int GEMM_BM = 128;
 

@@ -23,3 +23,15 @@ def test_parity_in_mode(gemm, lstm):
     print(r.stdout[-1500:])
     assert r.returncode == 0, r.stdout[-3000:]
     assert "'gemm': '%s'" % gemm in r.stdout and "'lstm': '%s'" % lstm in r.stdout
+
+
+def test_reduced_precision_fp16_mode():
+    """BSRNN_GEMM=fp16: plain fp16 operands, one MFMA term (the 16-bit compute configuration of BASELINE.json);
+    not fp32-accurate by design, held to 1e-2 of the largest reference value."""
+    env = dict(os.environ, BSRNN_GEMM="fp16", BSRNN_LSTM="fp16x2", BSRNN_TEST_RELTOL="1e-2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-s",
+                        "-k", "test_compute_mode_is_reported or test_forward_mask_vs_reference", "-p", "no:cacheprovider"],
+                       env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "'gemm': 'fp16'" in r.stdout

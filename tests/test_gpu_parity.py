@@ -12,8 +12,17 @@ import torch
 
 from conftest import golden
 
+import os
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+
+
+def tol_for(ref):
+    """1e-4 max-abs (north star) for every fp32-accurate mode; the reduced-precision fp16 GEMM mode (BASELINE config 2,
+    selected by tests/test_gpu_modes.py through BSRNN_TEST_RELTOL) is held to 1e-2 of the largest reference value."""
+    rel = float(os.environ.get("BSRNN_TEST_RELTOL", "0"))
+    return rel * float(np.abs(ref).max()) if rel > 0 else TOL
 
 
 def maxabs(a, b):
@@ -55,7 +64,7 @@ def test_forward_mask_vs_reference(name, which, request):
     y, mask = m.forward_with_mask(x)
     e_y, e_m = maxabs(t2n(y), g["y"]), maxabs(t2n(mask), g["mask"])
     print("%s: y err %.3e  mask err %.3e  (vs fp64 ref: %.3e)" % (name, e_y, e_m, maxabs(t2n(y), g["y64"])))
-    assert e_y < TOL and e_m < TOL
+    assert e_y < tol_for(g["y"]) and e_m < tol_for(g["mask"])
     assert torch.equal(m(x), y)                     # forward == forward_with_mask, deterministic
     assert x.equal(torch.from_numpy(g["x"]).cuda())  # input not modified
 
@@ -202,7 +211,7 @@ def test_errors_are_loud(model):
 def test_compute_mode_is_reported():
     from speechseparation_amd import _native
     m = _native.compute_mode()
-    assert m["gemm"] in ("f32", "fp16x2", "bf16x3") and m["lstm"] in ("f32", "fp16x2")
+    assert m["gemm"] in ("f32", "fp16x2", "bf16x3", "fp16") and m["lstm"] in ("f32", "fp16x2")
     print("compute mode:", m)
 
 
