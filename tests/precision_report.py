@@ -6,8 +6,8 @@ C-ABI in the mode given by the environment (BSRNN_GEMM / BSRNN_LSTM) and prints 
 the numpy oracle evaluated in float32 and in float64.  The float64 run is the exact answer up to 1e-15;
 the float32 oracle's own distance to it is the rounding noise any fp32 implementation carries.
 
-    BSRNN_GEMM=f32 BSRNN_LSTM=f32 python tools/precision_report.py
-    python tools/precision_report.py          # product default (fp16x2 split)
+    BSRNN_GEMM=f32 BSRNN_LSTM=f32 python tests/precision_report.py
+    python tests/precision_report.py          # product default (fp16x2 split)
 """
 import os
 import sys
