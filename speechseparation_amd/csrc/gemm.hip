@@ -724,8 +724,13 @@ __global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h
     constexpr int BN = 64 * NT;
     constexpr int PLANE = (BM + BN) * 32;           // halves per piece and stage: A rows then B rows, 64-byte rows
     constexpr int STAGE = NPL * PLANE;
-    constexpr int ES = BN + 4;
-    constexpr int SMEM_H = 2 * STAGE * 2 >= 64 * ES * 4 ? 2 * STAGE : 64 * ES * 2;      // two stages, or the epilogue staging tile if larger
+    constexpr int ES2 = BN + 4;                     // staging row stride (floats) of the two-pass epilogue
+    constexpr int SMEM_H = 2 * STAGE * 2 >= 64 * ES2 * 4 ? 2 * STAGE : 64 * ES2 * 2;    // two stages, or the epilogue staging tile if larger
+    // epilogues without extra operands stage the whole 128-row tile at once when LDS has room (one barrier pair, all four
+    // waves write); the residual / mask epilogues keep two 64-row passes (their prefetched rows would not fit in registers)
+    constexpr bool ONEPASS = (EPI == EPI_LEAKY || EPI == EPI_LINEAR) && SMEM_H * 2 >= BM * BN * 4;
+    constexpr int HP = ONEPASS ? 1 : 2, RPP = BM / HP;
+    constexpr int ES = !ONEPASS ? ES2 : (SMEM_H * 2 >= BM * (BN + 4) * 4 ? BN + 4 : BN);
     __shared__ __attribute__((aligned(16))) hT smemh[SMEM_H];
 
     const int m_tiles = (g.M + BM - 1) / BM;
@@ -931,9 +936,9 @@ __global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h
     float* const sE = reinterpret_cast<float*>(smemh);
     typedef const v4f __attribute__((address_space(1)))* gc4;
     typedef v4f __attribute__((address_space(1)))* g4;
-    constexpr int UPR4 = BN / 4, NU = 64 * UPR4 / 256;
+    constexpr int UPR4 = BN / 4, NU = RPP * UPR4 / 256;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < HP; ++hh) {
         if (hh) __syncthreads();
         // residual / multiplier rows of this half are requested before the accumulators go through LDS, so their
         // latency hides behind the staging and its barrier (the mask launch reads 134 MB this way)
@@ -943,14 +948,15 @@ __global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h
             for (int u = 0; u < NU; ++u) {
                 const int idx = tid + 256 * u;
                 const int row = idx / UPR4, c4 = idx % UPR4;
-                int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
+                int m = m0 + RPP * hh + row, n = n0 + 4 * c4;
                 m = m < M ? m : M - 1;
                 n = n < N ? n : 0;
                 rv[u] = *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
                 if (EPI == EPI_MASK) mv[u] = *(gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
             }
         }
-        if (wm == hh) {
+        if (ONEPASS || wm == hh) {
+            const int rb = ONEPASS ? 64 * wm : 0;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if (!live[j]) continue;
@@ -963,7 +969,7 @@ __global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h
                         float v = (TERMS == 1 ? acc[i][j][0][reg] : acc[i][j][0][reg] + (1.f / 2048.f) * acc[i][j][1][reg]) + bias[j];
                         if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
                         if (!in) v = 0.f;
-                        sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + col] = v;
+                        sE[(rb + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + col] = v;
                     }
             }
         }
@@ -972,7 +978,7 @@ __global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h
         for (int u = 0; u < NU; ++u) {
             const int idx = tid + 256 * u;
             const int row = idx / UPR4, c4 = idx % UPR4;
-            const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
+            const int m = m0 + RPP * hh + row, n = n0 + 4 * c4;
             if (m < M && n < ((N + 7) & ~7)) {
                 v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
                 if (EPI == EPI_RES || EPI == EPI_MASK) v += rv[u];
