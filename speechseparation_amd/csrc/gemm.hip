@@ -1,20 +1,22 @@
-// Grouped fp32 linear layers on the gfx950 matrix cores.
+// Grouped per-band linear layers on the gfx950 matrix cores.
 //
 // Replaces the ~110 nn.Linear calls of one BSRNN.forward (bsrnn.py:404-412, :422-425, and the
 // fc of NormRNNResidual :84) with one launch per "layer slot": a table of (band job, column
 // tile) x 128-row tiles of the M = C*T frame rows, walked in an XCD-aware order.
 //
-// Arithmetic is exact fp32: v_mfma_f32_32x32x2_f32 is a k-ordered fp32 fma chain (no xf32 on
-// gfx950), which is what the 1e-4 parity budget against the fp32 reference needs; bf16 MFMA
-// would be 16x faster and ~1e-2 wrong.  Roofline for this kernel is therefore the fp32
-// matrix peak (157.3 TFLOP/s), see DESIGN.md.
+// Three kernels, selected by launch_gemm() from BSRNN_GEMM (kernels.h, GemmMode):
+//   gemm_h2_kernel     (default, "fp16x2"; TERMS = 1: "fp16")  fp32 operands as two fp16 pieces, three MFMA terms on
+//                      v_mfma_f32_32x32x16_f16 with fp32 accumulation - fp32-level accuracy at 3/16 of the fp32
+//                      matrix-pipe time; pipelined main loop (two LDS stages, one barrier per slab);
+//   gemm_split_kernel  ("bf16x3", and the measurement variants of tools/gemm_planes_bench.hip)  generic split-
+//                      precision kernel: 2 fp16 or 3 bf16 pieces, operands split on the fly or pre-split planes;
+//   gemm_f32_kernel    ("f32")  exact fp32 on v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (no xf32 on gfx950).
+// All share the job / tile tables, the XCD mapping, the band-padded layouts (every segment 32-byte aligned, pad
+// columns zero) and the LDS-staged 16-byte epilogue with the fused bias / LeakyReLU / residual / mask variants.
 //
-// Tile: 128 x (64*NT) x BK per 256-thread workgroup, four waves as 2(M) x 2(N), each wave a
-// 64 x (32*NT) patch = 2*NT accumulators of 32x32.  NT = 2 (128-wide) is used for the slots whose
-// layers are wide: twice the MFMA work per barrier pair and per LDS byte (measured: the NT = 1
-// structure tops out at ~66 % of peak even with global loads removed).  NT = 1 serves the
-// 64-column layers.  Operands are K-contiguous in memory for both X [M][ldx] and W [N][K], so A
-// and B fragments are read with the same pattern: lane l owns row (l & 31) and the half (l >> 5)
+// gemm_f32_kernel: tile 128 x (64*NT) x BK per 256-thread workgroup, four waves as 2(M) x 2(N), each wave a
+// 64 x (32*NT) patch = 2*NT accumulators of 32x32.  Operands are K-contiguous in memory for both X [M][ldx] and
+// W [N][K], so A and B fragments are read with the same pattern: lane l owns row (l & 31) and the half (l >> 5)
 // of the BK-deep K slab, fetched as BK/8 ds_read_b128; MFMA step (j, e) consumes element e of the
 // j-th read, i.e. k = (BK/2)*(l>>5) + 4j + e on BOTH operands (the sum over k is order-agnostic as
 // long as A and B agree).  LDS rows are padded to BK+4 floats: (BK+4)/4 is odd, so the 16 rows of
