@@ -1,7 +1,12 @@
 // Dual-path recurrent kernels for gfx950: the band-axis BLSTM layer and the causal time-axis
 // two-layer LSTM of NormRNNResidual (bsrnn.py:63-98, BandwiseLSTM :131-162, TimewiseLSTM
-// :101-128).  fp32 throughout (exact-fp32 MFMA), torch gate order i,f,g,o:
+// :101-128).  torch gate order i,f,g,o:
 //     c' = sigmoid(f) c + sigmoid(i) tanh(g),  h' = sigmoid(o) tanh(c').
+// Two kernel families, selected by BSRNN_LSTM (kernels.h, LstmMode):
+//   *_h2_kernel (default, "fp16x2")  gate products on v_mfma_f32_16x16x32_f16 with both operands as two fp16 pieces
+//               (three MFMA terms, fp32 accumulation, fp32-level accuracy); cell state, activations and everything
+//               that leaves the kernel are fp32;
+//   *_kernel    ("f32")  exact fp32 on v_mfma_f32_16x16x4_f32 / 4x4x1.
 // fc_in (Linear 64->64, no activation) is folded into W_ih of layer 0 on the host
 // (api.hip: W' = W_ih W_in, b' = W_ih b_in + b_ih + b_hh, in double), the trailing fc + residual
 // runs as one grouped-GEMM launch (gemm.hip, EPI_RES).
