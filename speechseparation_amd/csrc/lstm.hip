@@ -29,6 +29,14 @@ __device__ __forceinline__ float fast_tanh(float x)
 {
     return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f;
 }
+__device__ __forceinline__ v4f exp2_4(const v4f x)
+{
+    return (v4f){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1]), __builtin_amdgcn_exp2f(x[2]), __builtin_amdgcn_exp2f(x[3])};
+}
+__device__ __forceinline__ v4f rcp4(const v4f x)
+{
+    return (v4f){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1]), __builtin_amdgcn_rcpf(x[2]), __builtin_amdgcn_rcpf(x[3])};
+}
 
 // =====================================================================================
 // Band-axis BLSTM layer.  grid = (ceil(N/16), 2 directions), 256 threads.
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     float bs[4];
 #pragma unroll
     for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[dir * 256 + gte * 64 + 16 * wave + l15];
-    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    v4f cv = {0.f, 0.f, 0.f, 0.f};               // cell states of this lane's four (sequence, unit) cells
 
     // x staging: XV float4 per thread: (row, 4 consecutive columns) -> 8 bytes of each piece
     const int xr_row[2] = {(tid * XV) / (IN / 4), (tid * XV + 1) / (IN / 4)};
@@ -335,20 +343,24 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         // cell update; C/D layout of the 16x16 MFMA: col (unit) = lane & 15, row (sequence) = 4*(lane>>4) + reg
         _Float16* const hp0 = &hpl[step & 1][0][((unit >> 3) * 16) * 8 + (unit & 7)];
         _Float16* const hp1 = &hpl[step & 1][1][((unit >> 3) * 16) * 8 + (unit & 7)];
+        {   // the four cells of this lane as 4-vectors: the adds / multiplies become v_pk_* (two per instruction),
+            // only the 5 exp + 5 rcp per cell stay scalar
+            const v4f pi = hi[0] + lo[0] * (1.f / 2048.f), pf = hi[1] + lo[1] * (1.f / 2048.f);
+            const v4f pg = hi[2] + lo[2] * (1.f / 2048.f), po = hi[3] + lo[3] * (1.f / 2048.f);
+            const v4f ig = rcp4(1.0f + exp2_4(pi * -1.44269504f)), fg = rcp4(1.0f + exp2_4(pf * -1.44269504f));
+            const v4f gg = 2.0f * rcp4(1.0f + exp2_4(pg * -2.88539008f)) - 1.0f, og = rcp4(1.0f + exp2_4(po * -1.44269504f));
+            cv = fg * cv + ig * gg;
+            const v4f hv4 = og * (2.0f * rcp4(1.0f + exp2_4(cv * -2.88539008f)) - 1.0f);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ig = fast_sigmoid(hi[0][r] + lo[0][r] * (1.f / 2048.f));
-            const float fg = fast_sigmoid(hi[1][r] + lo[1][r] * (1.f / 2048.f));
-            const float gg = fast_tanh(hi[2][r] + lo[2][r] * (1.f / 2048.f));
-            const float og = fast_sigmoid(hi[3][r] + lo[3][r] * (1.f / 2048.f));
-            c[r] = fg * c[r] + ig * gg;
-            const float hv = og * fast_tanh(c[r]);
-            const int m = 4 * q + r;
-            _Float16 p0, p1;
-            split_h2(hv, p0, p1);
-            hp0[m * 8] = p0;
-            hp1[m * 8] = p1;
-            if (n0 + m < N) hout[((size_t)(n0 + m) * L + t) * (2 * HID) + dir * HID + unit] = hv;
+            for (int r = 0; r < 4; ++r) {
+                const float hv = hv4[r];
+                const int m = 4 * q + r;
+                _Float16 p0, p1;
+                split_h2(hv, p0, p1);
+                hp0[m * 8] = p0;
+                hp1[m * 8] = p1;
+                if (n0 + m < N) hout[((size_t)(n0 + m) * L + t) * (2 * HID) + dir * HID + unit] = hv;
+            }
         }
         stamp(2);
         reset_acc();
