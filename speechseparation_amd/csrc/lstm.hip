@@ -267,11 +267,10 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     };
     auto tmap = [&](int step) { return dir ? L - 1 - step : step; };
 
+    // the first k block of a step starts from a zero C operand (an inline constant: no accumulator initialisation),
+    // the bias joins in the cell update
     v4f hi[4], lo[4];
-    auto reset_acc = [&]() {
-#pragma unroll
-        for (int gte = 0; gte < 4; ++gte) { hi[gte] = (v4f){bs[gte], bs[gte], bs[gte], bs[gte]}; lo[gte] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-    };
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
     const int frag = (q * 16 + l15) * 8;         // this lane's 16-byte unit inside a 32-deep block of a plane
     auto block_mfma = [&](const int b, const h8v a0, const h8v a1) {
         h8v w2[4];
@@ -279,9 +278,9 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         for (int gte = 0; gte < 4; ++gte)
             w2[gte] = b >= NB - NLDS ? __builtin_bit_cast(h8v, w2lds[((wave * NLDS + (b - (NB - NLDS))) * 4 + gte) * 64 + lane]) : w[b][gte][1];
 #pragma unroll
-        for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[b][gte][0], hi[gte], 0, 0, 0);
+        for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[b][gte][0], b == 0 ? zero4 : hi[gte], 0, 0, 0);
 #pragma unroll
-        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[b][gte][0], lo[gte], 0, 0, 0);
+        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[b][gte][0], b == 0 ? zero4 : lo[gte], 0, 0, 0);
 #pragma unroll
         for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w2[gte], lo[gte], 0, 0, 0);
     };
@@ -326,7 +325,6 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         if (L > 1) { xload(tmap(1), x0); xstore(1, x0); }
     }
     __syncthreads();
-    reset_acc();
     x_part(0);
     stamp(0);
 
@@ -345,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         _Float16* const hp1 = &hpl[step & 1][1][((unit >> 3) * 16) * 8 + (unit & 7)];
         {   // the four cells of this lane as 4-vectors: the adds / multiplies become v_pk_* (two per instruction),
             // only the 5 exp + 5 rcp per cell stay scalar
-            const v4f pi = hi[0] + lo[0] * (1.f / 2048.f), pf = hi[1] + lo[1] * (1.f / 2048.f);
-            const v4f pg = hi[2] + lo[2] * (1.f / 2048.f), po = hi[3] + lo[3] * (1.f / 2048.f);
+            const v4f pi = (hi[0] + lo[0] * (1.f / 2048.f)) + bs[0], pf = (hi[1] + lo[1] * (1.f / 2048.f)) + bs[1];
+            const v4f pg = (hi[2] + lo[2] * (1.f / 2048.f)) + bs[2], po = (hi[3] + lo[3] * (1.f / 2048.f)) + bs[3];
             const v4f ig = rcp4(1.0f + exp2_4(pi * -1.44269504f)), fg = rcp4(1.0f + exp2_4(pf * -1.44269504f));
             const v4f gg = 2.0f * rcp4(1.0f + exp2_4(pg * -2.88539008f)) - 1.0f, og = rcp4(1.0f + exp2_4(po * -1.44269504f));
             cv = fg * cv + ig * gg;
@@ -363,7 +361,6 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
             }
         }
         stamp(2);
-        reset_acc();
         if (step + 1 < L) x_part((step + 1) & 1);
         if (more2) xstore(step & 1, xn);         // slot of x_step, whose readers finished before the last barrier
         stamp(3);
