@@ -114,6 +114,32 @@ int  bsrnn_stft(bsrnn_ctx* ctx, const float* wave_dev, float* x_dev, int32_t R, 
 int  bsrnn_istft(bsrnn_ctx* ctx, const float* y_dev, float* wave_out_dev, int32_t R, int32_t T, void* stream);
 int  bsrnn_separate(bsrnn_ctx* ctx, const float* wave_dev, float* wave_out_dev, int32_t R, int64_t n, void* stream);
 
+/* ---- validation metrics (m_dataset.py:182-226 `infer` + `train_infer`, infer.py:44-47) ------
+ * bsrnn_evaluate: mix_dev [R, n] (the mixture, sample[0]) and speech_dev [R, n] (the clean target,
+ * sample[1]) -> separates the mixture (bsrnn_separate) and returns, in metrics_host[BSRNN_N_METRICS]:
+ *   LOSS          L1(x_time, s_time) + L1(Re X, Re S) + L1(Im X, Im S), each a mean over its elements
+ *                 (train.py:54 L1Loss; no discriminator term), S = STFT of the clean signal;
+ *   SDR           mean over rows of 10 log10((sum s^2 + 1e-9) / (sum (x - s)^2 + 1e-9)), s cut to len(x);
+ *   INPUT_SDR     the reference's `sdr2` exactly as written: its sample tensors are [1, R, n], so the sums
+ *                 run over the R rows and the mean over the n sample positions (m_dataset.py:219-222);
+ *   SISDR         scale-invariant SDR of torchmetrics (zero_mean = False, eps = float32 epsilon), mean over rows;
+ *   L1_TIME / L1_RE / L1_IM   the three loss terms;
+ *   SEPARATION_DB 10 ln(sum mix^2 / sum (mix - x)^2) over all rows (natural log, as infer.py:47 prints it).
+ * est_out_dev (optional) receives the separated signal [R, (T-1)*1024].  Synchronous: returns when the
+ * numbers are on the host.  Reductions accumulate in double on the device; rows are independent, so any R
+ * works (the reference's un-interleave hard-codes 2 rows, m_dataset.py:192). */
+#define BSRNN_M_LOSS          0
+#define BSRNN_M_SDR           1
+#define BSRNN_M_INPUT_SDR     2
+#define BSRNN_M_SISDR         3
+#define BSRNN_M_L1_TIME       4
+#define BSRNN_M_L1_RE         5
+#define BSRNN_M_L1_IM         6
+#define BSRNN_M_SEPARATION_DB 7
+#define BSRNN_N_METRICS       8
+int  bsrnn_evaluate(bsrnn_ctx* ctx, const float* mix_dev, const float* speech_dev, int32_t R, int64_t n,
+                    float* est_out_dev, double* metrics_host, void* stream);
+
 /* ---- streaming (infer-streaming.py:84-147; speech-ladspa-onnx.cpp:171-267) -------------
  * A bsrnn_stream owns, on the device, the sliding 2048-sample analysis buffer, the LSTM
  * state [4,2,C*K,64] and the previous synthesis frame for C rows.

@@ -238,6 +238,25 @@ class BSRNN(nn.Module):
             _check(_lib.bsrnn_separate(ctx, _ptr(w), _ptr(out), R, n, _stream_ptr(dev)))
         return out if waveform.is_cuda else out.cpu()
 
+    def evaluate(self, mix, speech, return_estimate=False):
+        """The reference's validation arithmetic on the device (m_dataset.py:182-226 `infer` + `train_infer` without
+        the discriminator, and the "Separation dB" of infer.py:44-47): mix, speech [R, n] -> dict of
+        loss / sdr / input_sdr / sisdr / l1_time / l1_re / l1_im / separation_db (see include/bsrnn_hip.h)."""
+        if mix.dim() != 2 or tuple(mix.shape) != tuple(speech.shape):
+            raise ValueError("expected mix and speech [R, n] of the same shape, got %s and %s" % (tuple(mix.shape), tuple(speech.shape)))
+        dev = self._device_for(mix)
+        m, s = self._prep(mix, dev), self._prep(speech, dev)
+        R, n = m.shape
+        vals = (ctypes.c_double * len(_native.METRIC_NAMES))()
+        with torch.cuda.device(dev):
+            ctx = self._context(dev)
+            est = torch.empty((R, (n // _spec.HOP) * _spec.HOP), device=dev, dtype=torch.float32) if return_estimate else None
+            _check(_lib.bsrnn_evaluate(ctx, _ptr(m), _ptr(s), R, n, _ptr(est) if return_estimate else None, vals, _stream_ptr(dev)))
+        out = {k: vals[i] for i, k in enumerate(_native.METRIC_NAMES)}
+        if return_estimate:
+            out["x_time"] = est if mix.is_cuda else est.cpu()
+        return out
+
     # ------------------------------------------------------------------ measurement
     def set_profiling(self, on, device=None):
         """on: False/True (all stages) or an iterable of stage names to bracket with events."""

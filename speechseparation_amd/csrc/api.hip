@@ -986,6 +986,90 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
     return 0;
 }
 
+// --------------------------------------------------------------------------- validation metrics
+// m_dataset.py:182-226 (`infer` + `train_infer` without the discriminator) and infer.py:44-47.
+int bsrnn_evaluate(bsrnn_ctx* c, const float* mix, const float* speech, int32_t R, int64_t n, float* est_out,
+                   double* metrics, void* stream)
+{
+    if (!metrics || !speech) return fail(BSRNN_EARG, "bsrnn_evaluate: null argument");
+    float* est = est_out;
+    double* d_part = nullptr;
+    float* d_alpha = nullptr;
+    const int T = 1 + (int)(n / HOPS);
+    const int64_t n_est = (int64_t)(T - 1) * HOPS;
+    int rc = 0;
+    auto cleanup = [&](int code) {
+        if (!est_out && est) (void)hipFree(est);
+        if (d_part) (void)hipFree(d_part);
+        if (d_alpha) (void)hipFree(d_alpha);
+        return code;
+    };
+    if ((rc = check_ready(c))) return rc;
+    if (!mix || R < 1 || n <= NFFT / 2) return fail(BSRNN_EARG, "bsrnn_evaluate: need n > 1024 samples, got %lld", (long long)n);
+    hipStream_t s = (hipStream_t)stream;
+    if (!est_out && hipMalloc((void**)&est, (size_t)R * n_est * sizeof(float)) != hipSuccess) {
+        est = nullptr;
+        return fail(BSRNN_EHIP, "bsrnn_evaluate: out of device memory");
+    }
+    // x_time and the estimate's spectrum (left in Yf, frame-major)                               m_dataset.py:186-195
+    if ((rc = bsrnn_separate(c, mix, est, R, n, stream))) return cleanup(rc);
+    // waveform_speech_freq: the clean signal through the same analysis (Xf is free once the mask launch ran)   :196
+    launch_stft(c->tb, speech, c->Xf, R, n, T, s);
+
+    const int chunks = metric_time_chunks(n_est), FB = 512, IB = 256;
+    const size_t n_time = (size_t)R * chunks * METRIC_TIME_Q, n_si = (size_t)R * chunks * 2, n_freq = (size_t)FB * 2, n_in = IB;
+    const size_t n_part = n_time + n_si + n_freq + n_in;
+    if (hipMalloc((void**)&d_part, n_part * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_alpha, R * sizeof(float)) != hipSuccess)
+        return cleanup(fail(BSRNN_EHIP, "bsrnn_evaluate: out of device memory"));
+    double *p_time = d_part, *p_si = p_time + n_time, *p_freq = p_si + n_si, *p_in = p_freq + n_freq;
+    launch_metric_time(est, speech, mix, R, n_est, n, p_time, s);
+    launch_metric_freq(c->tb, c->Yf, c->Xf, R * T, p_freq, FB, s);
+    launch_metric_input_sdr(speech, mix, R, n, p_in, IB, s);
+    std::vector<double> h(n_part);
+    if (hipMemcpyAsync(h.data(), d_part, (n_time) * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return cleanup(fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError())));
+    std::vector<double> q((size_t)R * METRIC_TIME_Q, 0.0);
+    for (int r = 0; r < R; ++r)
+        for (int ch = 0; ch < chunks; ++ch)
+            for (int i = 0; i < METRIC_TIME_Q; ++i) q[(size_t)r * METRIC_TIME_Q + i] += h[((size_t)r * chunks + ch) * METRIC_TIME_Q + i];
+    // SI-SDR: alpha = (<x, s> + eps) / (<s, s> + eps) in fp32, eps = float32 machine epsilon
+    const float eps = 1.1920928955078125e-07f;
+    std::vector<float> alpha(R);
+    for (int r = 0; r < R; ++r) alpha[r] = ((float)q[(size_t)r * METRIC_TIME_Q + 2] + eps) / ((float)q[(size_t)r * METRIC_TIME_Q + 0] + eps);
+    if (hipMemcpyAsync(d_alpha, alpha.data(), R * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess)
+        return cleanup(fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError())));
+    launch_metric_sisdr(est, speech, d_alpha, R, n_est, n, p_si, s);
+    if (hipMemcpyAsync(h.data() + n_time, p_si, (n_si + n_freq + n_in) * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return cleanup(fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError())));
+
+    double sdr = 0, sisdr = 0, l1_time = 0, m2 = 0, md2 = 0;
+    for (int r = 0; r < R; ++r) {
+        const double* qr = &q[(size_t)r * METRIC_TIME_Q];
+        sdr += 10.0 * log10((qr[0] + 1e-9) / (qr[1] + 1e-9));                                   // m_dataset.py:214-217
+        double ts2 = 0, nz2 = 0;
+        for (int ch = 0; ch < chunks; ++ch) { ts2 += h[n_time + ((size_t)r * chunks + ch) * 2]; nz2 += h[n_time + ((size_t)r * chunks + ch) * 2 + 1]; }
+        sisdr += 10.0 * log10((ts2 + (double)eps) / (nz2 + (double)eps));
+        l1_time += qr[4]; m2 += qr[5]; md2 += qr[6];
+    }
+    double l1_re = 0, l1_im = 0, in_sdr = 0;
+    for (int b = 0; b < FB; ++b) { l1_re += h[n_time + n_si + 2 * b]; l1_im += h[n_time + n_si + 2 * b + 1]; }
+    for (int b = 0; b < IB; ++b) in_sdr += h[n_time + n_si + n_freq + b];
+    l1_time /= (double)R * (double)n_est;                                                      // L1Loss(reduction='mean'), train.py:54
+    l1_re /= (double)R * NBINS * T;
+    l1_im /= (double)R * NBINS * T;
+    metrics[BSRNN_M_LOSS] = l1_time + l1_re + l1_im;                                           // m_dataset.py:211-213
+    metrics[BSRNN_M_SDR] = sdr / R;
+    metrics[BSRNN_M_INPUT_SDR] = in_sdr / (double)n;
+    metrics[BSRNN_M_SISDR] = sisdr / R;
+    metrics[BSRNN_M_L1_TIME] = l1_time;
+    metrics[BSRNN_M_L1_RE] = l1_re;
+    metrics[BSRNN_M_L1_IM] = l1_im;
+    metrics[BSRNN_M_SEPARATION_DB] = 10.0 * log(m2 / md2);                                     // natural log, infer.py:47
+    const hipError_t e = hipGetLastError();
+    return cleanup(e == hipSuccess ? 0 : fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(e)));
+}
+
 // --------------------------------------------------------------------------- streaming
 int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
 {

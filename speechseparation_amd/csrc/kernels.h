@@ -106,4 +106,15 @@ void launch_stream_analysis(const FftTables& tb, float* buf, const float* chunk,
 void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, const float* mix_dev,
                              float* prev, float* out, int C, hipStream_t s);
 
+// ------------------------------------------------------------------ validation metrics (metrics.hip)
+// Per-workgroup partial sums in double; the host adds them.  est [R][n_est]; speech, mix [R][n_in] (first n_est used).
+constexpr int METRIC_TIME_Q = 7;     // sum s^2, (x-s)^2, x*s, x^2, |x-s|, m^2, (m-x)^2
+int metric_time_chunks(int64_t n_est);                                   // workgroups per row of the two row-wise kernels
+void launch_metric_time(const float* est, const float* speech, const float* mix, int R, int64_t n_est, int64_t n_in,
+                        double* part /* [R][chunks][7] */, hipStream_t s);
+void launch_metric_sisdr(const float* est, const float* speech, const float* alpha /* [R] */, int R, int64_t n_est, int64_t n_in,
+                         double* part /* [R][chunks][2] */, hipStream_t s);
+void launch_metric_input_sdr(const float* speech, const float* mix, int R, int64_t n, double* part /* [blocks] */, int blocks, hipStream_t s);
+void launch_metric_freq(const FftTables& tb, const float* Yf, const float* Sf, int M, double* part /* [blocks][2] */, int blocks, hipStream_t s);
+
 }  // namespace bsrnn

@@ -182,3 +182,30 @@ def test_infer_streaming_cli(tmp_path, sd_default):
     assert float(np.abs(got.numpy() - ref).max()) < 1e-4
     v, sd2 = weights.load_flat(str(tmp_path / "hello.bsrnnw"))
     assert all(np.array_equal(sd2[k], sd_default[k]) for k in sd_default)
+
+
+def test_validate_cli(tmp_path, sd_default):
+    """validate.py: the reference's validation block (train.py:132-150) over file pairs; averages against the oracle."""
+    from oracle import metrics_torch as mt
+    from oracle.bsrnn_torch_cpu import TorchCpuBSRNN
+    from speechseparation_amd import spec, weights
+    oracle = TorchCpuBSRNN(sd_default, spec.generate_bandsplits()[0])
+    files, refs = [], []
+    for i, n in enumerate((16000 + 7, 3 * 4096)):
+        mix = weights.synth_waveform(2, n, seed=60 + i)
+        speech = weights.synth_waveform(2, n, seed=70 + i, scale=0.05)
+        pm, ps = str(tmp_path / ("mix%d.wav" % i)), str(tmp_path / ("speech%d.wav" % i))
+        _write_wav(pm, mix, 16000)
+        _write_wav(ps, speech, 16000)
+        files += [pm, ps]
+        refs.append(mt.train_infer(oracle.forward, torch.from_numpy(mix), torch.from_numpy(speech)))
+    out = subprocess.run([sys.executable, os.path.join(REPO, "validate.py"), "--pairs"] + files + ["--synthetic-weights", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode == 0, out.stderr
+    words = out.stdout.split()
+    loss = float(words[words.index("Loss") + 1])
+    sdr = float(words[words.index("SDR") + 1])
+    sisdr = float(words[words.index("SI-SDR") + 1])
+    assert abs(loss - np.mean([r["loss"] for r in refs])) < 1e-4
+    assert abs(sdr - np.mean([r["sdr"] for r in refs])) < 2e-3
+    assert abs(sisdr - np.mean([r["sisdr"] for r in refs])) < 2e-3
