@@ -108,3 +108,30 @@ def test_generators_are_deterministic():
     assert 0.09 < float(w1.std()) < 0.11
     # pinned first values (any change here invalidates the golden fixtures)
     assert w1[0, :3].tolist() == weights.synth_waveform(1, 3, seed=1234)[0].tolist()
+
+
+def test_reference_checkpoint_interchange(tmp_path, built):
+    """A checkpoint written the way the reference writes it (train.py:171: torch.save(model.state_dict(), ...)) loads into the
+    host class through the safe loader, converts to the flat file of the C ABI / plugin and back without changing a bit."""
+    import sys
+    from collections import OrderedDict
+    from speechseparation_amd import audio
+    from speechseparation_amd.bsrnn import BSRNN
+    sd = weights.synth_state_dict(None, seed=4)
+    pth, flat, back = str(tmp_path / "model-always.pth"), str(tmp_path / "m.bsrnnw"), str(tmp_path / "back.pth")
+    torch.save(OrderedDict((k, torch.from_numpy(a.copy())) for k, a in sd.items()), pth)
+    m = BSRNN()
+    assert audio.load_model_weights(m, pth) == pth
+    got = m.state_dict()
+    assert all(np.array_equal(got[k].numpy(), sd[k]) for k in sd)
+    tool = os.path.join(REPO, "tools", "convert_weights.py")
+    subprocess.run([sys.executable, tool, pth, flat], check=True, capture_output=True)
+    v, sd2 = weights.load_flat(flat)
+    assert v == spec.generate_bandsplits()[0] and list(sd2) == list(spec.param_spec()) and all(np.array_equal(sd2[k], sd[k]) for k in sd)
+    subprocess.run([sys.executable, tool, flat, back], check=True, capture_output=True)
+    sd3 = torch.load(back, map_location="cpu", weights_only=True)
+    assert all(np.array_equal(sd3[k].numpy(), sd[k]) for k in sd)
+    # a checkpoint of another architecture is refused, not half-loaded
+    bad = str(tmp_path / "bad.pth")
+    torch.save(OrderedDict(list((k, torch.from_numpy(a.copy())) for k, a in sd.items())[:-1]), bad)
+    assert subprocess.run([sys.executable, tool, bad, flat], capture_output=True).returncode != 0
