@@ -145,21 +145,45 @@ __device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const S
     irfft_store(r, sc, z, tid);
 }
 
+// Frames per workgroup of the two offline kernels.  All workgroups of a launch cost the same, so a grid slightly larger
+// than the chip's resident capacity (CUs x workgroups per CU) runs as two rounds with the second nearly empty: at
+// R = 64, T = 126 six frames per workgroup gave 1344 workgroups for 1024 (STFT) / 768 (iSTFT) slots.  The chunk length
+// is chosen per launch to minimise rounds x (frames walked per workgroup); small inputs get short chunks (more
+// workgroups), `extra` = frames a chunk recomputes (the iSTFT's overlap frame).
+static int resident_slots(const void* kernel)
+{
+    int dev = 0, cus = 256, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    return cus * per_cu;
+}
+static int frames_per_workgroup(int units, int rows, int slots, int extra)
+{
+    int best = 4;
+    long best_cost = -1;
+    for (int L = 16; L >= 4; --L) {
+        const long wgs = (long)((units + L - 1) / L) * rows;
+        const long cost = ((wgs + slots - 1) / slots) * (L + extra);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = L; }
+    }
+    return best;
+}
+
 // ------------------------------------------------------------------------------ offline STFT
-// One workgroup transforms SCH consecutive frames of one row.  Frames overlap by half: the thread that owns complex
+// One workgroup transforms `sch` consecutive frames of one row.  Frames overlap by half: the thread that owns complex
 // samples c + 512, c + 768 of frame t owns c, c + 256 of frame t + 1, so only the new half is loaded per frame
 // (requested before the FFT passes of the current frame) and the raw samples stay in registers.
-constexpr int SCH = 6;
 __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __restrict__ wave, float* __restrict__ X,
-                                                   int64_t n, int T)
+                                                   int64_t n, int T, int sch)
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<false>(tb.tw1024, tid);
     const SplitCtx spl = load_split(tb, tid, false);
     const int r = blockIdx.y;
-    const int t0 = blockIdx.x * SCH;
-    const int t1 = (t0 + SCH < T) ? t0 + SCH : T;
+    const int t0 = blockIdx.x * sch;
+    const int t1 = (t0 + sch < T) ? t0 + sch : T;
     const float* src = wave + (size_t)r * n;
     float2 win[4];
 #pragma unroll
@@ -193,27 +217,28 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
 
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s)
 {
-    dim3 grid((unsigned)((T + SCH - 1) / SCH), R);
-    hipLaunchKernelGGL(stft_kernel, grid, dim3(256), 0, s, tb, wave, X, n, T);
+    static const int slots = resident_slots((const void*)stft_kernel);
+    const int sch = frames_per_workgroup(T, R, slots, 0);
+    dim3 grid((unsigned)((T + sch - 1) / sch), R);
+    hipLaunchKernelGGL(stft_kernel, grid, dim3(256), 0, s, tb, wave, X, n, T, sch);
 }
 
 // ------------------------------------------------------------------------------ offline iSTFT
-// One workgroup produces ICH consecutive output hops of one row: output hop b = first half of synthesis frame
+// One workgroup produces `ich` consecutive output hops of one row: output hop b = first half of synthesis frame
 // b + 1 + second half of frame b, divided by the window envelope (torch.istft).  The workgroup walks frames
-// b0 .. b0 + ICH, keeps the windowed second half of the previous frame in registers (the thread that owns complex
+// b0 .. b0 + ich, keeps the windowed second half of the previous frame in registers (the thread that owns complex
 // samples c, c + 256 of a frame's first half also owns c + 512, c + 768 of the second half) and recomputes one
 // frame per chunk - no [M][2048] frame buffer in HBM and no separate overlap-add launch (was 132 MB + 15 us).
 // The spectrum of frame t + 1 is requested before the FFT passes of frame t.
-constexpr int ICH = 6;
-__global__ __launch_bounds__(256) void istft_fused_kernel(FftTables tb, const float* __restrict__ Y, float* __restrict__ out, int T)
+__global__ __launch_bounds__(256) void istft_fused_kernel(FftTables tb, const float* __restrict__ Y, float* __restrict__ out, int T, int ich)
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<true>(tb.tw1024, tid);
     const SplitCtx spl = load_split(tb, tid, true);
     const int r = blockIdx.y;
-    const int b0 = blockIdx.x * ICH;
-    const int b1 = (b0 + ICH < T - 1) ? b0 + ICH : T - 1;          // output hops [b0, b1) <- frames b0 .. b1
+    const int b0 = blockIdx.x * ich;
+    const int b1 = (b0 + ich < T - 1) ? b0 + ich : T - 1;          // output hops [b0, b1) <- frames b0 .. b1
     const size_t len = (size_t)(T - 1) * HOPS;
     const float sc = 1.0f / 1024.0f;
     float2 wlo[2], whi[2], env[2], carry[2];
@@ -251,8 +276,10 @@ __global__ __launch_bounds__(256) void istft_fused_kernel(FftTables tb, const fl
 void launch_istft(const FftTables& tb, const float* Y, float* out, int R, int T, hipStream_t s)
 {
     if (T < 2) return;
-    dim3 grid((unsigned)((T - 1 + ICH - 1) / ICH), R);
-    hipLaunchKernelGGL(istft_fused_kernel, grid, dim3(256), 0, s, tb, Y, out, T);
+    static const int slots = resident_slots((const void*)istft_fused_kernel);
+    const int ich = frames_per_workgroup(T - 1, R, slots, 1);
+    dim3 grid((unsigned)((T - 1 + ich - 1) / ich), R);
+    hipLaunchKernelGGL(istft_fused_kernel, grid, dim3(256), 0, s, tb, Y, out, T, ich);
 }
 
 // ------------------------------------------------------------------------------ [C][2050][T] <-> [C*T][ld]
