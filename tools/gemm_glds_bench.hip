@@ -19,7 +19,9 @@ typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
 // NST = LDS stages (2: one slab in flight, 3: two).  ABL: 1 = no DMA after the prologue, 2 = no MFMA.
-template <int EPI, int NST, int ABL = 0, int BMT = 128>
+// TR = 1: MFMA operands swapped, so the accumulators hold the transposed 32x32 tiles - a lane owns 4 x 4 consecutive
+// output columns of one row and stores them with 16-byte global stores straight from registers (no LDS staging, no barriers).
+template <int EPI, int NST, int ABL = 0, int BMT = 128, int TR = 0>
 __global__ __launch_bounds__(2 * BMT, (BMT == 128 ? 2 : 1)) void gemm_glds_kernel(GemmLaunch g, const _Float16* __restrict__ Xs, int ldxs, const int* __restrict__ xs_off)
 {
     typedef _Float16 hT;
@@ -128,6 +130,12 @@ __global__ __launch_bounds__(2 * BMT, (BMT == 128 ? 2 : 1)) void gemm_glds_kerne
                 if (!FAST && !live[j]) continue;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+                    if (TR) {
+                        acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks][j][0], a[ks][i][1], acc[i][j][1], 0, 0, 0);
+                        acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks][j][1], a[ks][i][0], acc[i][j][1], 0, 0, 0);
+                        acc[i][j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks][j][0], a[ks][i][0], acc[i][j][0], 0, 0, 0);
+                        continue;
+                    }
                     acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][1], b[ks][j][0], acc[i][j][1], 0, 0, 0);
                     acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][0], b[ks][j][1], acc[i][j][1], 0, 0, 0);
                     acc[i][j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][0], b[ks][j][0], acc[i][j][0], 0, 0, 0);
@@ -173,9 +181,36 @@ __global__ __launch_bounds__(2 * BMT, (BMT == 128 ? 2 : 1)) void gemm_glds_kerne
         }
     }
 
+    typedef v4f __attribute__((address_space(1)))* g4;
+    if (TR) {
+        // lane (row = lane & 31 of the 32-row block, half) holds columns 8 q + 4 half + 0..3 of the 32-column block in regs 4q..4q+3
+        typedef const v4f __attribute__((address_space(1)))* gc4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (!live[j]) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wcol + 32 * j + 8 * q + 4 * half;
+                if (n >= ((N + 7) & ~7)) continue;
+                const v4f bv = *(gc4)((gcf)job.bias + (n + 3 < N ? n : 0));     // (probe: widths are multiples of 8)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = m0 + 64 * wm + 32 * i + r32;
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][0][4 * q + e] + (1.f / 2048.f) * acc[i][j][1][4 * q + e] + bv[e];
+                        if (EPI == EPI_LEAKY) x = x >= 0.f ? x : 0.01f * x;
+                        v[e] = n + e < N ? x : 0.f;
+                    }
+                    if (m < M) *(g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
+                }
+            }
+        }
+        return;
+    }
     // epilogue through LDS in passes of 128 rows, fp32 output
     float* const sE = reinterpret_cast<float*>(smemh);
-    typedef v4f __attribute__((address_space(1)))* g4;
     constexpr int ES = BN, UPR4 = BN / 4, NU = 128 * UPR4 / NTH;
 #pragma unroll
     for (int pass = 0; pass < BM / 128; ++pass) {
@@ -208,7 +243,7 @@ __global__ __launch_bounds__(2 * BMT, (BMT == 128 ? 2 : 1)) void gemm_glds_kerne
     }
 }
 
-template <int NST, int ABL = 0, int BMT = 128>
+template <int NST, int ABL = 0, int BMT = 128, int TR = 0>
 static void launch_glds(const GemmLaunch& g_in, const _Float16* Xs, int ldxs, const int* xs_off, hipStream_t stream)
 {
     GemmLaunch g = g_in;
@@ -216,7 +251,7 @@ static void launch_glds(const GemmLaunch& g_in, const _Float16* Xs, int ldxs, co
     g.mchunk = BMT == 128 ? gemm_mchunk(m_tiles) : 1;
     const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
     dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(2 * BMT);
-    hipLaunchKernelGGL((gemm_glds_kernel<EPI_LEAKY, NST, ABL, BMT>), grid, block, 0, stream, g, Xs, ldxs, xs_off);
+    hipLaunchKernelGGL((gemm_glds_kernel<EPI_LEAKY, NST, ABL, BMT, TR>), grid, block, 0, stream, g, Xs, ldxs, xs_off);
 }
 
 int main(int argc, char** argv)
@@ -297,10 +332,10 @@ int main(int argc, char** argv)
     CK(hipStreamCreate(&s));
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    constexpr int NV = 10;
+    constexpr int NV = 11;
     const char* names[NV] = {"product (A split on the fly, register staging)", "LDS-DMA, 2 stages", "LDS-DMA, 3 stages", "LDS-DMA 2 stages, no DMA after prologue",
                              "LDS-DMA 2 stages, no MFMA", "LDS-DMA 3 stages, no MFMA", "LDS-DMA 256x128 tile, 8 waves, 2 stages", "LDS-DMA 256x128 tile, 8 waves, 3 stages",
-                             "LDS-DMA 256x128 3 stages, no DMA after prologue", "LDS-DMA 256x128 3 stages, no MFMA"};
+                             "LDS-DMA 256x128 3 stages, no DMA after prologue", "LDS-DMA 256x128 3 stages, no MFMA", "LDS-DMA 2 stages, transposed acc, direct stores"};
     std::vector<float> t[NV];
     for (int rep = 0; rep < 14; ++rep)
         for (int v = 0; v < NV; ++v) {
@@ -315,7 +350,8 @@ int main(int argc, char** argv)
             case 6: launch_glds<2, 0, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s); break;
             case 7: launch_glds<3, 0, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s); break;
             case 8: launch_glds<3, 1, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s); break;
-            default: launch_glds<3, 2, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s); }
+            case 9: launch_glds<3, 2, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s); break;
+            default: launch_glds<2, 0, 128, 1>(g2, (const _Float16*)dXs, ldxs, dXoff, s); }
             CK(hipEventRecord(b, s));
             CK(hipEventSynchronize(b));
             float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -331,11 +367,12 @@ int main(int argc, char** argv)
     CK(hipStreamSynchronize(s));
     std::vector<float> y0(xn), y1(xn);
     CK(hipMemcpy(y0.data(), dY, xn * 4, hipMemcpyDeviceToHost));
-    for (int v : {1, 2, 6, 7}) {
+    for (int v : {1, 2, 6, 7, 10}) {
         CK(hipMemset(dY2, 0, xn * 4));
         if (v == 1) launch_glds<2>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         else if (v == 2) launch_glds<3>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         else if (v == 6) launch_glds<2, 0, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
+        else if (v == 10) launch_glds<2, 0, 128, 1>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         else launch_glds<3, 0, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(y1.data(), dY2, xn * 4, hipMemcpyDeviceToHost));
