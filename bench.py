@@ -53,6 +53,20 @@ def exact_macs(v):
             "time_lstm": time_, "time_fc": 2 * K * H * H}
 
 
+def gemm_activation_bytes(v):
+    """Algorithmic activation bytes per row-frame of the ten grouped-GEMM launches (fp32: every layer reads its
+    input once and writes its output once; the last one also reads the residual and the spectrum it multiplies).
+    The per-band layers are only 2*K flop per activation byte deep, so this is a second floor beside the matrix pipe."""
+    H = 64
+    a = [2 * w for w in v if w]
+    m = [max(x, H) for x in a]
+    p = [max(x, 2 * H) for x in a]
+    n = len(a)
+    cols = (sum(a) + sum(a)) + (sum(a) + sum(a)) + (sum(a) + sum(m)) + (sum(m) + n * H) + (n * H + n * H)        # PRE0 PRE2 FC0 FC2 FC4
+    cols += (n * H + n * 2 * H) + (n * 2 * H + sum(p)) + (sum(p) + sum(a)) + (sum(a) + sum(a)) + (sum(a) + 3 * sum(a))   # BACK0 BACK2 BACK4 POST0 POST2
+    return 4 * cols
+
+
 def host_cores():
     """Threads for the CPU baseline: this process's share of the box (affinity and cgroup quota),
     capped at BSRNN_CPU_THREADS (default 16 = one GPU's CPU share on the bench pool; asking
@@ -241,6 +255,10 @@ def main():
                     "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms_step / n_launch, 4), "launches_per_step": n_launch,
                     "flop_per_launch_avg": dom_flop_step / n_launch, "peak_basis": basis,
                     "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "hbm_view": {"algorithmic_bytes_per_launch_avg": gemm_activation_bytes(spec.generate_bandsplits()[0]) * rf / n_launch,
+                                 "achieved_GBs": round(gemm_activation_bytes(spec.generate_bandsplits()[0]) * rf / (dom_ms_step * 1e-3) / 1e9, 1),
+                                 "frac_of_hbm_peak": round(gemm_activation_bytes(spec.generate_bandsplits()[0]) * rf / (dom_ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "note": "the same launches against HBM: activations in + out per layer (2*K flop per byte only), weights excluded"},
                     "note": "achieved = algorithmic flops (2 x MACs of the Linear layers x row-frames, fp32 semantics) / launch time; "
                             "HIP events on the launch stream over the timed region"}
         dp_ms = sum(per_step.get(k, 0.0) for k in ("band_lstm", "band_fc", "time_lstm", "time_fc"))
