@@ -80,6 +80,15 @@ int  bsrnn_commit_params(bsrnn_ctx* ctx);
  * speech-ladspa-onnx.cpp:73 opens.  Does set_param for every tensor, then commit. */
 int  bsrnn_load_weights_file(bsrnn_ctx* ctx, const char* path);
 
+/* I/O signature of the one-frame model, as the reference's exported ONNX file declares it (infer-streaming.py:74
+ * `torch.onnx.export(..., (x, state))`; read back by the plugin, speech-ladspa-onnx.cpp:82-111, which sizes its state
+ * buffers from the shape of the input named "state.0"): index 0 "x.0" [C, 2050] and 1 "state.0" [4, 2, C*K, 64] are
+ * inputs, 2 "y.0" [C, 2050] and 3 "new_state.0" [4, 2, C*K, 64] outputs.  Hosts written against that session API can
+ * size and name their tensors from here instead of from a model file; C is the caller's row count (2 in the plugin). */
+int  bsrnn_io_count(void);
+int  bsrnn_io_info(const bsrnn_ctx* ctx, int32_t index, int32_t C, const char** name, int32_t* is_input,
+                   int64_t dims[4], int32_t* ndim);
+
 /* ---- model entry points ---------------------------------------------------------------
  * bsrnn_forward            = BSRNN.forward            (bsrnn.py:385-443)
  *     x_dev [C, 2050, T] -> y_dev [C, 2050, T]   (y = x * mask; x is not modified)

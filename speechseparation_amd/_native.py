@@ -18,7 +18,7 @@ SYMBOLS = [
     "bsrnn_stft", "bsrnn_istft", "bsrnn_separate", "bsrnn_stream_create", "bsrnn_stream_destroy", "bsrnn_stream_reset",
     "bsrnn_stream_step", "bsrnn_stream_step_host", "bsrnn_stream_get_state", "bsrnn_set_profiling", "bsrnn_stage_count",
     "bsrnn_stage_name", "bsrnn_stage_times", "bsrnn_dev_alloc", "bsrnn_dev_free", "bsrnn_copy_h2d", "bsrnn_copy_d2h",
-    "bsrnn_sync", "bsrnn_evaluate",
+    "bsrnn_sync", "bsrnn_evaluate", "bsrnn_io_count", "bsrnn_io_info",
 ]
 METRIC_NAMES = ("loss", "sdr", "input_sdr", "sisdr", "l1_time", "l1_re", "l1_im", "separation_db")   # BSRNN_M_* order
 
@@ -76,6 +76,8 @@ def _load():
         "bsrnn_copy_d2h": (C.c_int, [vp, vp, vp, i64]),
         "bsrnn_sync": (C.c_int, [vp, vp]),
         "bsrnn_evaluate": (C.c_int, [vp, vp, vp, i32, i64, vp, C.POINTER(C.c_double), vp]),
+        "bsrnn_io_count": (C.c_int, []),
+        "bsrnn_io_info": (C.c_int, [vp, i32, i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

@@ -841,6 +841,19 @@ int bsrnn_load_weights_file(bsrnn_ctx* c, const char* path)
     return bsrnn_commit_params(c);
 }
 
+// --------------------------------------------------------------------------- I/O signature (the exported ONNX file's)
+int bsrnn_io_count(void) { return 4; }
+int bsrnn_io_info(const bsrnn_ctx* c, int32_t index, int32_t C, const char** name, int32_t* is_input, int64_t dims[4], int32_t* ndim)
+{
+    static const char* const kNames[4] = {"x.0", "state.0", "y.0", "new_state.0"};      // infer-streaming.py:74 (torch.onnx.export naming)
+    if (!c || index < 0 || index >= 4 || C < 1 || !dims || !ndim) return fail(BSRNN_EARG, "bsrnn_io_info: bad arguments");
+    if (name) *name = kNames[index];
+    if (is_input) *is_input = index < 2;
+    if (index & 1) { dims[0] = 4; dims[1] = 2; dims[2] = (int64_t)C * c->K; dims[3] = HID; *ndim = 4; }
+    else { dims[0] = C; dims[1] = F2; dims[2] = dims[3] = 0; *ndim = 2; }
+    return 0;
+}
+
 // --------------------------------------------------------------------------- model entry points
 int bsrnn_forward(bsrnn_ctx* c, const float* x, float* y, float* mask, int32_t C, int32_t T, void* stream)
 {

@@ -135,3 +135,28 @@ def test_reference_checkpoint_interchange(tmp_path, built):
     bad = str(tmp_path / "bad.pth")
     torch.save(OrderedDict(list((k, torch.from_numpy(a.copy())) for k, a in sd.items())[:-1]), bad)
     assert subprocess.run([sys.executable, tool, bad, flat], capture_output=True).returncode != 0
+
+
+@pytest.mark.gpu
+def test_io_signature_matches_the_exported_onnx_naming(built):
+    """bsrnn_io_info: names and shapes of the reference's ONNX export (infer-streaming.py:74; speech-ladspa-onnx.cpp:82-111
+    sizes its state from the input called "state.0").  (A context needs a HIP device, hence the gpu mark.)"""
+    from speechseparation_amd import _native
+    lib = _native.lib
+    v = spec.generate_bandsplits()[0]
+    ctx = ctypes.c_void_p()
+    widths = (ctypes.c_int32 * len(v))(*v)
+    assert lib.bsrnn_create(0, widths, len(v), ctypes.byref(ctx)) == 0, lib.bsrnn_last_error().decode()
+    try:
+        assert lib.bsrnn_io_count() == 4
+        got = []
+        for i in range(4):
+            name, is_in, nd = ctypes.c_char_p(), ctypes.c_int32(), ctypes.c_int32()
+            dims = (ctypes.c_int64 * 4)()
+            assert lib.bsrnn_io_info(ctx, i, 2, ctypes.byref(name), ctypes.byref(is_in), dims, ctypes.byref(nd)) == 0
+            got.append((name.value.decode(), bool(is_in.value), tuple(dims[:nd.value])))
+        assert got == [("x.0", True, (2, 2050)), ("state.0", True, (4, 2, 24, 64)),
+                       ("y.0", False, (2, 2050)), ("new_state.0", False, (4, 2, 24, 64))]
+        assert lib.bsrnn_io_info(ctx, 4, 2, None, None, (ctypes.c_int64 * 4)(), ctypes.byref(ctypes.c_int32())) != 0
+    finally:
+        lib.bsrnn_destroy(ctx)
