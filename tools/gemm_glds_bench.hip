@@ -209,6 +209,28 @@ __global__ __launch_bounds__(2 * BMT, (BMT == 128 ? 2 : 1)) void gemm_glds_kerne
         }
         return;
     }
+    if (TR == 2) {
+        // natural accumulator layout, 4-byte stores straight from registers: a wave instruction writes two rows x 32
+        // consecutive columns = two full 128-byte lines; no LDS staging, no barriers
+        typedef float __attribute__((address_space(1)))* g1;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (!live[j]) continue;
+            const int n = n0 + wcol + 32 * j + r32;
+            if (n >= ((N + 7) & ~7)) continue;
+            const bool in = n < N;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = m0 + 64 * wm + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    float v = acc[i][j][0][reg] + (1.f / 2048.f) * acc[i][j][1][reg] + bias[j];
+                    if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
+                    if (m < M) *((g1)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = in ? v : 0.f;
+                }
+        }
+        return;
+    }
     // epilogue through LDS in passes of 128 rows, fp32 output
     float* const sE = reinterpret_cast<float*>(smemh);
     constexpr int ES = BN, UPR4 = BN / 4, NU = 128 * UPR4 / NTH;
@@ -332,10 +354,10 @@ int main(int argc, char** argv)
     CK(hipStreamCreate(&s));
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    constexpr int NV = 11;
+    constexpr int NV = 12;
     const char* names[NV] = {"product (A split on the fly, register staging)", "LDS-DMA, 2 stages", "LDS-DMA, 3 stages", "LDS-DMA 2 stages, no DMA after prologue",
                              "LDS-DMA 2 stages, no MFMA", "LDS-DMA 3 stages, no MFMA", "LDS-DMA 256x128 tile, 8 waves, 2 stages", "LDS-DMA 256x128 tile, 8 waves, 3 stages",
-                             "LDS-DMA 256x128 3 stages, no DMA after prologue", "LDS-DMA 256x128 3 stages, no MFMA", "LDS-DMA 2 stages, transposed acc, direct stores"};
+                             "LDS-DMA 256x128 3 stages, no DMA after prologue", "LDS-DMA 256x128 3 stages, no MFMA", "LDS-DMA 2 stages, transposed acc, direct stores", "LDS-DMA 2 stages, direct 4-byte stores"};
     std::vector<float> t[NV];
     for (int rep = 0; rep < 14; ++rep)
         for (int v = 0; v < NV; ++v) {
@@ -351,7 +373,8 @@ int main(int argc, char** argv)
             case 7: launch_glds<3, 0, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s); break;
             case 8: launch_glds<3, 1, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s); break;
             case 9: launch_glds<3, 2, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s); break;
-            default: launch_glds<2, 0, 128, 1>(g2, (const _Float16*)dXs, ldxs, dXoff, s); }
+            case 10: launch_glds<2, 0, 128, 1>(g2, (const _Float16*)dXs, ldxs, dXoff, s); break;
+            default: launch_glds<2, 0, 128, 2>(g2, (const _Float16*)dXs, ldxs, dXoff, s); }
             CK(hipEventRecord(b, s));
             CK(hipEventSynchronize(b));
             float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -367,12 +390,13 @@ int main(int argc, char** argv)
     CK(hipStreamSynchronize(s));
     std::vector<float> y0(xn), y1(xn);
     CK(hipMemcpy(y0.data(), dY, xn * 4, hipMemcpyDeviceToHost));
-    for (int v : {1, 2, 6, 7, 10}) {
+    for (int v : {1, 2, 6, 7, 10, 11}) {
         CK(hipMemset(dY2, 0, xn * 4));
         if (v == 1) launch_glds<2>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         else if (v == 2) launch_glds<3>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         else if (v == 6) launch_glds<2, 0, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         else if (v == 10) launch_glds<2, 0, 128, 1>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
+        else if (v == 11) launch_glds<2, 0, 128, 2>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         else launch_glds<3, 0, 256>(g2, (const _Float16*)dXs, ldxs, dXoff, s);
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(y1.data(), dY2, xn * 4, hipMemcpyDeviceToHost));
