@@ -172,10 +172,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # Rehearsal on a one-GPU box (not a measurement): BSRNN_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for
+    # the barrier / max-reduce, so the whole multi-rank script path can be exercised without an 8-GPU node.
+    rehearse = os.environ.get("BSRNN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
@@ -222,7 +230,7 @@ def main():
     stages = model.stage_times(reset=True)
     model.set_profiling(False, device)
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearse else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
