@@ -279,7 +279,7 @@ def main():
             "metric": "separated row-frames/sec, batch64 8s@16kHz",
             "value": round(value, 1), "unit": "row-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if cmode["gemm"] != "fp16" else "f16 (fp32 accumulate)", "data": "synthetic",
+            "dtype": "f32" if cmode["gemm"] != "fp16" else "f16 (fp32 accumulate)", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks share cuda:0 over gloo; not a measurement)",
             "config": {"workload": "offline separate (STFT->BSRNN.forward->iSTFT), %d rows/GPU x %d samples @16 kHz (T=%d), K=12 bands, fp32"
                                    % (args.rows, args.samples, T),
                        "rows_per_gpu": args.rows, "global_rows": args.rows * world, "frames": T, "parallelism": "dp%d (row shards, no in-path collective)" % world},
