@@ -67,6 +67,7 @@ struct bsrnn_ctx {
     // activation column layout
     std::vector<int> aoff, poff;
     int LDA = 0, LDP = 0;
+    bool slab_flow = false;         // fp16x2 mode: A1 / A2 hold slab-format (pre-split) activations
 
     // device-resident weights and tables
     float* d_arena = nullptr;
@@ -291,12 +292,15 @@ int ensure_streams(bsrnn_ctx* c, int parts)
     return 0;
 }
 
+// xs / ys: the layer's input / output is the slab-format view of X / Y (an A1 / A2 buffer; fp16x2 mode only)
 void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ldy, const float* R, int ldr,
-               const float* Mul, int ldm, float* tap, int M, int epi, hipStream_t s)
+               const float* Mul, int ldm, float* tap, int M, int epi, hipStream_t s, bool xs = false, bool ys = false)
 {
     GemmLaunch g;
     memset(&g, 0, sizeof g);
-    g.out_mode = 1;
+    g.out_mode = ys ? 4 : 1;
+    if (xs) { g.Xs = X; g.ldxs = 2 * ldx; }
+    if (ys) { g.Ys = Y; g.ldys = 2 * ldy; }
     g.range_flag = c->d_range;
     g.jobs = c->d_jobs + c->job0[slot];
     g.tiles = c->d_tiles + c->tile0[slot];
@@ -346,11 +350,14 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         break;
     case MS_BANDSPLIT: {   // bandFCs_pre (2 linears) -> residual P; bandFCs (3 linears) -> Z0   bsrnn.py:404-415
         StageScope sc(c, ST_BANDSPLIT, s);
-        gemm_slot(c, PRE0, p.Xf, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, PRE2, p.A1, c->LDA, p.P, c->LDP, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, FC0, p.P, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, FC2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, FC4, p.A2, c->LDA, p.Z0, KH, nullptr, 0, nullptr, 0, nullptr, M, EPI_LINEAR, s);
+        // fp16x2 mode: the intermediates A1 / A2 travel pre-split in slab format (sl): written by the producer's
+        // epilogue, copied to LDS by DMA in the consumer (gemm_h2s_kernel)
+        const bool sl = c->slab_flow;
+        gemm_slot(c, PRE0, p.Xf, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, false, sl);
+        gemm_slot(c, PRE2, p.A1, c->LDA, p.P, c->LDP, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, false);
+        gemm_slot(c, FC0, p.P, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, false, sl);
+        gemm_slot(c, FC2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, sl);
+        gemm_slot(c, FC4, p.A2, c->LDA, p.Z0, KH, nullptr, 0, nullptr, 0, nullptr, M, EPI_LINEAR, s, sl, false);
         break;
     }
     case MS_BAND0: case MS_BAND1: {   // BandwiseLSTM: N = M sequences of length K   bsrnn.py:138-153
@@ -382,11 +389,12 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     }
     case MS_MASK: {   // bandFCs_back (3) + bandFCs_back_post (2) + skip + x*mask   bsrnn.py:420-443
         StageScope sc(c, ST_MASK, s);
-        gemm_slot(c, BACK0, p.Z0, KH, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, BACK2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, BACK4, p.A2, c->LDA, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, POST0, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
-        gemm_slot(c, POST2, p.A2, c->LDA, p.Yf, c->LDP, p.P, c->LDP, p.Xf, c->LDP, p.tap, M, EPI_MASK, s);
+        const bool sl = c->slab_flow;
+        gemm_slot(c, BACK0, p.Z0, KH, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, false, sl);
+        gemm_slot(c, BACK2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, sl);
+        gemm_slot(c, BACK4, p.A2, c->LDA, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, sl);
+        gemm_slot(c, POST0, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, sl);
+        gemm_slot(c, POST2, p.A2, c->LDA, p.Yf, c->LDP, p.P, c->LDP, p.Xf, c->LDP, p.tap, M, EPI_MASK, s, sl, false);
         break;
     }
     case MS_ISTFT:
@@ -465,7 +473,9 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
     int pos = 0, ao = 0, po = 0;
     for (int i = 0; i < n_bands; ++i) {
         c->off.push_back(pos); pos += widths[i];
-        c->aoff.push_back(ao); ao += round8(imax(2 * widths[i], 2 * HID));
+        // 32-column granularity: the same per-band offsets (x 2, in 16-bit elements) address the slab-format activations,
+        // whose bands are padded to whole 32-deep slabs
+        c->aoff.push_back(ao); ao += (imax(2 * widths[i], 2 * HID) + 31) & ~31;
         c->poff.push_back(po); po += round8(2 * widths[i]);
     }
     c->LDA = ao; c->LDP = imax(po, 8);
@@ -476,6 +486,12 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
         if (e != hipSuccess) { c->h_range = nullptr; c->d_range = nullptr; (void)hipGetLastError(); }
     }
     if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(1, std::min(MAX_PARTS, atoi(e)));
+    {   // BSRNN_GEMM_SLAB=1 (opt-in, fp16x2 mode): the MLP intermediates travel pre-split in slab format and the consuming
+        // layers run on gemm_h2s_kernel (LDS-DMA staging).  Bit-identical results; measured in the pipeline at R = 64:
+        // bandsplit +0.5 %, mask +3 % SLOWER than splitting on the fly (10 % faster on an isolated launch), so it is off.
+        const char* e = getenv("BSRNN_GEMM_SLAB");
+        c->slab_flow = gemm_mode() == GEMM_FP16X2 && e && !strcmp(e, "1");
+    }
     if (const char* e = getenv("BSRNN_PART_LAG")) c->part_lag = std::max(0, std::min((int)MS_COUNT, atoi(e)));
     memset(c->acc_ms, 0, sizeof c->acc_ms);
     memset(c->acc_n, 0, sizeof c->acc_n);
@@ -633,6 +649,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         jb.push_back(ar.put(bi.data));
         jwp.push_back(put_planes(wp, N, Kp));
         j.wrow = h2_row_stride((Kp + 31) & ~31);
+        j.xs_off = 2 * x_off; j.ys_off = 2 * y_off;      // slab-format A1 / A2 (used by the slots that run on them, see run_stage)
         jobs.push_back(j);
     };
     auto begin_slot = [&](int slot) { c->job0[slot] = (int)jobs.size(); c->tile0[slot] = (int)tiles.size(); };

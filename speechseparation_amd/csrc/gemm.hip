@@ -702,6 +702,120 @@ static void launch_gemm_split(const GemmLaunch& g_in, hipStream_t stream)
 //   * rows are 64 bytes without padding, 16-byte units XOR-swizzled with (row >> 2) & 3, which keeps both the
 //     ds_read_b128 fragment reads and the stage at 32 KB (two stages + two workgroups per CU fit in 160 KB).
 // =====================================================================================
+// Epilogue of the fp16x2 kernels: accumulators -> LDS -> 16-byte global stores (whole lines per row), with the fused
+// bias / LeakyReLU / residual / mask variants.  Output as fp32 rows (out_mode & 1) and / or pre-split for the next layer
+// in the weights' slab format (out_mode & 4, LEAKY only: see GemmLaunch::Ys) - the split then happens once per element
+// in the producer instead of once per element and column tile in the consumer.  `omax` returns the largest |value|
+// written as slabs (range guard of the fp16 pieces).
+template <int EPI, int NT, int TERMS, int SMEM_H>
+__device__ __forceinline__ void h2_epilogue(const GemmLaunch& g, const GemmJob& job, v16f (&acc)[2][NT][2], const float (&bias)[NT],
+                                            const bool (&live)[NT], _Float16* smemh, const int m0, const int n0, const int tid, float& omax)
+{
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int BN = 64 * NT;
+    constexpr int ES2 = BN + 4;                     // staging row stride (floats) of the two-pass epilogue
+    // epilogues without extra operands stage the whole 128-row tile at once when LDS has room (one barrier pair, all four
+    // waves write); the residual / mask epilogues keep two 64-row passes (their prefetched rows would not fit in registers)
+    constexpr bool ONEPASS = (EPI == EPI_LEAKY || EPI == EPI_LINEAR) && SMEM_H * 2 >= BM * BN * 4;
+    constexpr int HP = ONEPASS ? 1 : 2, RPP = BM / HP;
+    constexpr int ES = !ONEPASS ? ES2 : (SMEM_H * 2 >= BM * (BN + 4) * 4 ? BN + 4 : BN);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, r32 = lane & 31;
+    const int wcol = 32 * NT * wn;
+    const int N = job.N, M = g.M;
+    float* const sE = reinterpret_cast<float*>(smemh);
+    typedef const v4f __attribute__((address_space(1)))* gc4;
+    typedef v4f __attribute__((address_space(1)))* g4;
+    typedef h8 __attribute__((address_space(1)))* gh8_;
+    constexpr int UPR4 = BN / 4, NU = RPP * UPR4 / 256;
+#pragma unroll
+    for (int hh = 0; hh < HP; ++hh) {
+        if (hh) __syncthreads();
+        // residual / multiplier rows of this half are requested before the accumulators go through LDS, so their
+        // latency hides behind the staging and its barrier (the mask launch reads 134 MB this way)
+        v4f rv[NU], mv[NU];
+        if (EPI == EPI_RES || EPI == EPI_MASK) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = tid + 256 * u;
+                const int row = idx / UPR4, c4 = idx % UPR4;
+                int m = m0 + RPP * hh + row, n = n0 + 4 * c4;
+                m = m < M ? m : M - 1;
+                n = n < N ? n : 0;
+                rv[u] = *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
+                if (EPI == EPI_MASK) mv[u] = *(gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
+            }
+        }
+        if (ONEPASS || wm == hh) {
+            const int rb = ONEPASS ? 64 * wm : 0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!live[j]) continue;
+                const int col = wcol + 32 * j + r32;
+                const bool in = n0 + col < N;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float v = (TERMS == 1 ? acc[i][j][0][reg] : acc[i][j][0][reg] + (1.f / 2048.f) * acc[i][j][1][reg]) + bias[j];
+                        if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
+                        if (!in) v = 0.f;
+                        sE[(rb + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + col] = v;
+                    }
+            }
+        }
+        __syncthreads();
+        if ((EPI == EPI_LEAKY) && (g.out_mode & 4)) {
+            // slabs: 8 consecutive columns of a row = 16 bytes of each piece; the 4 units of a 32-deep slab and their
+            // second pieces make one 128-byte line.  Columns up to the next multiple of 32 beyond N are zeros (they
+            // lie in a live 32-column block, staged as zeros above).
+            constexpr int UPR8 = BN / 8;
+            const int nlim = (N + 31) & ~31;
+            const gh8_ Ys = (gh8_)((_Float16 __attribute__((address_space(1)))*)g.Ys + job.ys_off);
+#pragma unroll
+            for (int u = 0; u < RPP * UPR8 / 256; ++u) {
+                const int idx = tid + 256 * u;
+                const int row = idx / UPR8, c8 = idx % UPR8;
+                const int m = m0 + RPP * hh + row, n = n0 + 8 * c8;
+                if (m < M && n < nlim) {
+                    const v4f lo = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8]), hi = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8 + 4]);
+                    omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fabsf(lo[0])), __builtin_fabsf(lo[1]));
+                    omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fabsf(lo[2])), __builtin_fabsf(lo[3]));
+                    omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fabsf(hi[0])), __builtin_fabsf(hi[1]));
+                    omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fabsf(hi[2])), __builtin_fabsf(hi[3]));
+                    h4 p[2], q[2];
+                    Piece<2>::split(lo, p);
+                    Piece<2>::split(hi, q);
+                    const h8 p0 = {p[0][0], p[0][1], p[0][2], p[0][3], q[0][0], q[0][1], q[0][2], q[0][3]};
+                    const h8 p1 = {p[1][0], p[1][1], p[1][2], p[1][3], q[1][0], q[1][1], q[1][2], q[1][3]};
+                    _Float16 __attribute__((address_space(1)))* const d = (_Float16 __attribute__((address_space(1)))*)Ys + (size_t)m * g.ldys + (n >> 5) * 64 + (n & 31);
+                    *(gh8_)d = p0;
+                    *(gh8_)(d + 32) = p1;
+                }
+            }
+        }
+        if (!(EPI == EPI_LEAKY) || (g.out_mode & 1)) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int idx = tid + 256 * u;
+                const int row = idx / UPR4, c4 = idx % UPR4;
+                const int m = m0 + RPP * hh + row, n = n0 + 4 * c4;
+                if (m < M && n < ((N + 7) & ~7)) {
+                    v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
+                    if (EPI == EPI_RES || EPI == EPI_MASK) v += rv[u];
+                    if (EPI == EPI_MASK) {
+                        if (g.tap) *(g4)((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
+                        v *= mv[u];
+                    }
+                    *(g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
+                }
+            }
+        }
+    }
+}
+
 template <int NVALU>
 __device__ __forceinline__ void sched_slice()
 {
@@ -726,13 +840,7 @@ __global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h
     constexpr int BN = 64 * NT;
     constexpr int PLANE = (BM + BN) * 32;           // halves per piece and stage: A rows then B rows, 64-byte rows
     constexpr int STAGE = NPL * PLANE;
-    constexpr int ES2 = BN + 4;                     // staging row stride (floats) of the two-pass epilogue
-    constexpr int SMEM_H = 2 * STAGE * 2 >= 64 * ES2 * 4 ? 2 * STAGE : 64 * ES2 * 2;    // two stages, or the epilogue staging tile if larger
-    // epilogues without extra operands stage the whole 128-row tile at once when LDS has room (one barrier pair, all four
-    // waves write); the residual / mask epilogues keep two 64-row passes (their prefetched rows would not fit in registers)
-    constexpr bool ONEPASS = (EPI == EPI_LEAKY || EPI == EPI_LINEAR) && SMEM_H * 2 >= BM * BN * 4;
-    constexpr int HP = ONEPASS ? 1 : 2, RPP = BM / HP;
-    constexpr int ES = !ONEPASS ? ES2 : (SMEM_H * 2 >= BM * (BN + 4) * 4 ? BN + 4 : BN);
+    constexpr int SMEM_H = 2 * STAGE * 2 >= 64 * (BN + 4) * 4 ? 2 * STAGE : 64 * (BN + 4) * 2;    // two stages, or the epilogue staging tile if larger
     __shared__ __attribute__((aligned(16))) hT smemh[SMEM_H];
 
     const int m_tiles = (g.M + BM - 1) / BM;
@@ -932,66 +1040,9 @@ __global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h
         for (; k0 < K; k0 += 32) step(std::false_type(), k0);
     }
 
-    if (!(amax <= 65504.f) && g.range_flag) *g.range_flag = 1;     // also catches NaN / Inf inputs
-
-    // epilogue through LDS, fp32 output (16-byte units, whole lines per row)
-    float* const sE = reinterpret_cast<float*>(smemh);
-    typedef const v4f __attribute__((address_space(1)))* gc4;
-    typedef v4f __attribute__((address_space(1)))* g4;
-    constexpr int UPR4 = BN / 4, NU = RPP * UPR4 / 256;
-#pragma unroll
-    for (int hh = 0; hh < HP; ++hh) {
-        if (hh) __syncthreads();
-        // residual / multiplier rows of this half are requested before the accumulators go through LDS, so their
-        // latency hides behind the staging and its barrier (the mask launch reads 134 MB this way)
-        v4f rv[NU], mv[NU];
-        if (EPI == EPI_RES || EPI == EPI_MASK) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int idx = tid + 256 * u;
-                const int row = idx / UPR4, c4 = idx % UPR4;
-                int m = m0 + RPP * hh + row, n = n0 + 4 * c4;
-                m = m < M ? m : M - 1;
-                n = n < N ? n : 0;
-                rv[u] = *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
-                if (EPI == EPI_MASK) mv[u] = *(gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
-            }
-        }
-        if (ONEPASS || wm == hh) {
-            const int rb = ONEPASS ? 64 * wm : 0;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (!live[j]) continue;
-                const int col = wcol + 32 * j + r32;
-                const bool in = n0 + col < N;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        float v = (TERMS == 1 ? acc[i][j][0][reg] : acc[i][j][0][reg] + (1.f / 2048.f) * acc[i][j][1][reg]) + bias[j];
-                        if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
-                        if (!in) v = 0.f;
-                        sE[(rb + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + col] = v;
-                    }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int idx = tid + 256 * u;
-            const int row = idx / UPR4, c4 = idx % UPR4;
-            const int m = m0 + RPP * hh + row, n = n0 + 4 * c4;
-            if (m < M && n < ((N + 7) & ~7)) {
-                v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
-                if (EPI == EPI_RES || EPI == EPI_MASK) v += rv[u];
-                if (EPI == EPI_MASK) {
-                    if (g.tap) *(g4)((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
-                    v *= mv[u];
-                }
-                *(g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
-            }
-        }
-    }
+    float omax = 0.f;
+    h2_epilogue<EPI, NT, TERMS, SMEM_H>(g, job, acc, bias, live, smemh, m0, n0, tid, omax);
+    if (!(__builtin_fmaxf(amax, omax) <= 65504.f) && g.range_flag) *g.range_flag = 1;     // also catches NaN / Inf
 }
 
 template <int NT, int ABL = 0, int TERMS = 3>
@@ -1007,6 +1058,166 @@ static void launch_gemm_h2(const GemmLaunch& g_in, hipStream_t stream)
     case EPI_LEAKY:  hipLaunchKernelGGL((gemm_h2_kernel<EPI_LEAKY, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
     case EPI_RES:    hipLaunchKernelGGL((gemm_h2_kernel<EPI_RES, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
     default:         hipLaunchKernelGGL((gemm_h2_kernel<EPI_MASK, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
+    }
+}
+
+// =====================================================================================
+// gemm_h2s_kernel: the fp16x2 layer whose INPUT arrives pre-split in slab format (written by the previous layer's
+// epilogue, h2_epilogue out_mode & 4).  Both operands are then fragment-ready in memory, and the whole staging is
+// LDS-DMA: global_load_lds_dwordx4 copies 16 rows x 64 bytes of one piece per instruction straight into the stage
+// (lane-linear LDS image, the 16-byte unit swizzle of the fragment reads applied to the source address) - no staging
+// registers, no split VALU, no ds_write in the main loop.  Same tile geometry, job / tile tables, XCD mapping, LDS
+// layout, MFMA order (bit-identical results) and epilogue as gemm_h2_kernel; two stages, the next slab's copies are
+// issued at the top of a k-step and retired by the vmcnt(0) of its closing barrier.
+// Measured in isolation (tools/gemm_glds_bench.hip, profiles/r01i_gemm_glds_probe.txt): 74 vs 82 us on the PRE0-shaped launch.
+// =====================================================================================
+template <int EPI, int NT>
+__global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2s_kernel(GemmLaunch g)
+{
+    typedef _Float16 hT;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int BN = 64 * NT;
+    constexpr int PLANE = (BM + BN) * 32;           // halves per piece and stage: A rows then B rows, 64-byte rows
+    constexpr int STAGE = 2 * PLANE;
+    constexpr int SMEM_H = 2 * STAGE * 2 >= 64 * (BN + 4) * 4 ? 2 * STAGE : 64 * (BN + 4) * 2;
+    __shared__ __attribute__((aligned(16))) hT smemh[SMEM_H];
+
+    const int m_tiles = (g.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
+    const int mchunk = g.mchunk;
+    const int per_chunk = mchunk * g.n_tiles;
+    const int chunk = (lidx / per_chunk) * 8 + xcd;
+    const int rem = lidx % per_chunk;
+    const int m_tile = chunk * mchunk + rem % mchunk;
+    if (m_tile >= m_tiles) return;
+    const int2 tj = g.tiles[rem / mchunk];
+    const GemmJob job = g.jobs[tj.x];
+    const int n0 = tj.y * BN;
+    const int m0 = m_tile * BM;
+    const int N = job.N, K = job.K, M = g.M;
+    const int nk = (K + 31) >> 5;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, r32 = lane & 31;
+    const int wcol = 32 * NT * wn;
+    float bias[NT];
+    bool live[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nc = n0 + wcol + 32 * j + r32;
+        bias[j] = ((gcf)job.bias)[nc < N ? nc : N - 1];
+        live[j] = (n0 + wcol + 32 * j) < N;
+    }
+
+    // copy plan of this wave: activation rows 32 wave .. + 31 (two groups of 16) and weight rows BN/4 * wave .. (BG groups)
+    typedef const char __attribute__((address_space(1)))* gcc;
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    constexpr int BG = BN / 64;
+    const int lrow = lane >> 2, slot = lane & 3;
+    unsigned srcA[2], srcB[BG];                      // byte offsets of this lane's unit in piece 0 of slab 0
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r = 32 * wave + 16 * s + lrow;
+        int ra = m0 + r; ra = ra < M ? ra : M - 1;
+        srcA[s] = ((unsigned)ra * (unsigned)g.ldxs + (unsigned)job.xs_off + 8u * (unsigned)(slot ^ ((r >> 2) & 3))) * 2u;
+    }
+#pragma unroll
+    for (int s = 0; s < BG; ++s) {
+        const int r = 16 * BG * wave + 16 * s + lrow;
+        int rb = n0 + r; rb = rb < N ? rb : N - 1;
+        srcB[s] = ((unsigned)rb * (unsigned)job.wrow + 8u * (unsigned)(slot ^ ((r >> 2) & 3))) * 2u;
+    }
+    const gcc Ab = (gcc)g.Xs, Bb = (gcc)job.Wp;
+    auto dma = [&](int ks, hT* st) {
+        const unsigned kb = (unsigned)ks * 128u;     // one slab = 128 bytes per row
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                __builtin_amdgcn_global_load_lds((glb_vp)(Ab + (srcA[s] + kb + 64u * pl)), (lds_vp)(st + pl * PLANE + (32 * wave + 16 * s) * 32), 16, 0, 0);
+#pragma unroll
+            for (int s = 0; s < BG; ++s)
+                __builtin_amdgcn_global_load_lds((glb_vp)(Bb + (srcB[s] + kb + 64u * pl)), (lds_vp)(st + pl * PLANE + (BM + 16 * BG * wave + 16 * s) * 32), 16, 0, 0);
+        }
+    };
+
+    v16f acc[2][NT][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { acc[i][j][0] = (v16f){0}; acc[i][j][1] = (v16f){0}; }
+    const int swz = (r32 >> 2) & 3;
+    const int fa = (64 * wm + r32) * 32, fb = (BM + wcol + r32) * 32;
+    const int fu[2] = {((0 + half) ^ swz) * 8, ((2 + half) ^ swz) * 8};
+
+    // one slab: the first half's fragment reads, then the second half's reads one behind each of the first MFMAs
+    // (one exposed LDS latency per slab), then the remaining MFMAs
+    auto compute = [&](auto fast_tag, const hT* cur) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        h8 b[2][NT][2], a[2][2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[ks][j][pl] = *reinterpret_cast<const h8*>(&cur[pl * PLANE + fb + 32 * j * 32 + fu[ks]]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[ks][i][pl] = *reinterpret_cast<const h8*>(&cur[pl * PLANE + fa + 32 * i * 32 + fu[ks]]);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!FAST && !live[j]) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][1], b[ks][j][0], acc[i][j][1], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][0], b[ks][j][1], acc[i][j][1], 0, 0, 0);
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][0], b[ks][j][0], acc[i][j][0], 0, 0, 0);
+                }
+            }
+        if (FAST) {
+            constexpr int NR = 2 * (NT + 2);         // fragment reads per half
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 12 * NT - NR, 0);
+        }
+    };
+    const bool fast = live[NT - 1];
+    if (nk > 0) dma(0, smemh);
+    __syncthreads();                                // (with the vmcnt(0) that retires the copies)
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) dma(ks + 1, smemh + ((ks + 1) & 1) * STAGE);
+        if (fast) compute(std::true_type(), smemh + (ks & 1) * STAGE);
+        else if (live[0]) compute(std::false_type(), smemh + (ks & 1) * STAGE);
+        __syncthreads();
+    }
+
+    float omax = 0.f;
+    h2_epilogue<EPI, NT, 3, SMEM_H>(g, job, acc, bias, live, smemh, m0, n0, tid, omax);
+    if (!(omax <= 65504.f) && g.range_flag) *g.range_flag = 1;
+}
+
+template <int NT>
+static void launch_gemm_h2s(const GemmLaunch& g_in, hipStream_t stream)
+{
+    GemmLaunch g = g_in;
+    const int m_tiles = (g.M + BM - 1) / BM;
+    g.mchunk = gemm_mchunk(m_tiles);
+    const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
+    dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(256);
+    switch (g.epilogue) {
+    case EPI_LINEAR: hipLaunchKernelGGL((gemm_h2s_kernel<EPI_LINEAR, NT>), grid, block, 0, stream, g); break;
+    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_h2s_kernel<EPI_LEAKY, NT>), grid, block, 0, stream, g); break;
+    case EPI_RES:    hipLaunchKernelGGL((gemm_h2s_kernel<EPI_RES, NT>), grid, block, 0, stream, g); break;
+    default:         hipLaunchKernelGGL((gemm_h2s_kernel<EPI_MASK, NT>), grid, block, 0, stream, g); break;
     }
 }
 
@@ -1046,6 +1257,11 @@ void launch_gemm(const GemmLaunch& g, hipStream_t stream)
     if (g.M <= 0 || g.n_tiles <= 0) return;
     switch (gemm_mode()) {
     case GEMM_FP16X2:
+        if (g.Xs) {                                  // input pre-split by the producing layer: LDS-DMA kernel
+            if (g.tile_n == 128) launch_gemm_h2s<2>(g, stream);
+            else launch_gemm_h2s<1>(g, stream);
+            return;
+        }
         if (g.tile_n == 128) launch_gemm_h2<2>(g, stream);
         else launch_gemm_h2<1>(g, stream);
         return;

@@ -24,6 +24,7 @@ struct GemmJob {
     int r_off;           // column offset inside the residual row (EPI_RES, EPI_MASK)
     int m_off;           // column offset inside the multiplier / mask-tap row (EPI_MASK)
     int wrow;            // fp16x2 slab format: 16-bit elements between consecutive weight rows of Wp
+    int xs_off, ys_off;  // slab-format activations (GemmLaunch::Xs / Ys): 16-bit element offset of the job's first slab in a row
 };
 
 enum GemmEpilogue {
@@ -50,7 +51,12 @@ struct GemmLaunch {
     // starts p * plane elements after the first; columns use the same offsets and ld as X / Y
     const void* Xp; size_t xp_plane;   // input planes; null: X is fp32 and is split on the fly
     void* Yp; size_t yp_plane;         // output planes (written when out_mode & 2)
-    int out_mode;                      // bit 0: write fp32 Y, bit 1: write planes Yp
+    int out_mode;                      // bit 0: write fp32 Y, bit 1: write planes Yp, bit 2: write slabs Ys
+    // fp16x2 mode, activations pre-split by the producing layer's epilogue in the weights' slab format
+    // [row][K32 / 32][2 pieces][32] fp16 (both pieces of a 32-deep slab of a row share one 128-byte line; columns from
+    // N up to the next multiple of 32 are written as zeros): the consumer copies them global -> LDS by LDS-DMA.
+    const void* Xs; int ldxs;          // input slabs (null: X is fp32 and is split on the fly); ld in 16-bit elements
+    void* Ys; int ldys;                // output slabs (written when out_mode & 4)
     int* range_flag;                   // fp16x2: set to 1 when an operand exceeded the fp16 range (may be null)
 };
 void launch_gemm(const GemmLaunch& g, hipStream_t stream);
