@@ -98,7 +98,12 @@ struct bsrnn_ctx {
     hipStream_t last_stream = nullptr;
 
     // concurrent row blocks of one call (bsrnn_separate)
-    int n_parts = 1, part_lag = 0;     // BSRNN_PARTS / BSRNN_PART_LAG; measured at R=64: 2 parts = +1.8 %, more = worse
+    // BSRNN_PARTS / BSRNN_PART_LAG.  0 = automatic: one block below 128 rows (at R = 64 two half-size blocks gain 2 %, but
+    // the stage brackets and kernel durations of concurrent blocks overlap, which blurs the per-kernel accounting), two
+    // blocks of >= 64 rows from 128 rows on: each block keeps full-size launches and the other block's matrix work fills
+    // the latency-bound time-axis LSTM (+8-12 % at 128 rows).  Rows are independent; tests/test_gpu_edges.py checks a
+    // 130-row call bit for bit against its row blocks.  (That check first failed: see the note at the top of fft.hip.)
+    int n_parts = 0, part_lag = 0;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -485,7 +490,7 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
         if (e == hipSuccess) { *c->h_range = 0; e = hipHostGetDevicePointer((void**)&c->d_range, c->h_range, 0); }
         if (e != hipSuccess) { c->h_range = nullptr; c->d_range = nullptr; (void)hipGetLastError(); }
     }
-    if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(1, std::min(MAX_PARTS, atoi(e)));
+    if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(0, std::min(MAX_PARTS, atoi(e)));
     {   // BSRNN_GEMM_SLAB=1 (opt-in, fp16x2 mode): the MLP intermediates travel pre-split in slab format and the consuming
         // layers run on gemm_h2s_kernel (LDS-DMA staging).  Bit-identical results; measured in the pipeline at R = 64:
         // bandsplit +0.5 %, mask +3 % SLOWER than splitting on the fly (10 % faster on an isolated launch), so it is off.
@@ -986,7 +991,7 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
     // stage sequence concurrently on separate streams: the ramps, tails and latency-bound stages of
     // one block (e.g. the time-axis LSTM occupies 192 of 256 CUs) overlap matrix work of the other.
     // Part j starts `lag` stages behind part j-1 so that they sit in different stages.
-    int parts = c->n_parts;
+    int parts = c->n_parts > 0 ? c->n_parts : (R >= 128 ? 2 : 1);
     if (R < 2 * parts || (int64_t)R * T < 2048) parts = 1;
     if (parts > 1 && (rc = ensure_streams(c, parts))) return rc;
     Part pt[MAX_PARTS];

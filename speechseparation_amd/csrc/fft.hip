@@ -8,6 +8,8 @@
 // frame); their loads and stores are coalesced along the frame.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace bsrnn {
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -145,6 +147,13 @@ __device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const S
     irfft_store(r, sc, z, tid);
 }
 
+// NOTE: this file is compiled with -fno-slp-vectorize (csrc/Makefile).  With the SLP vectorizer the complex butterflies
+// become packed-fp32 (v_pk_*) code, and the STFT / iSTFT kernels then returned garbage in whole frames whenever kernels of
+// another process or of another stream of this process shared the GPU - always right when alone.  Found with
+// tools/row_block_check.py and tests/coresident_check.py; bisected to the FFT passes (not the barriers, the twiddle loads,
+// the LDS neighbours or the counted waits) and to the vectorizer (-O1 and -O3 -fno-slp-vectorize are clean, -O2 / -O3 are
+// not).  The scalar code is as fast.
+//
 // Frames per workgroup of the two offline kernels.  All workgroups of a launch cost the same, so a grid slightly larger
 // than the chip's resident capacity (CUs x workgroups per CU) runs as two rounds with the second nearly empty: at
 // R = 64, T = 126 six frames per workgroup gave 1344 workgroups for 1024 (STFT) / 768 (iSTFT) slots.  The chunk length
@@ -160,6 +169,8 @@ static int resident_slots(const void* kernel)
 }
 static int frames_per_workgroup(int units, int rows, int slots, int extra)
 {
+    static const int forced = [] { const char* e = getenv("BSRNN_FFT_RUN"); return e ? atoi(e) : 0; }();      // measurement / debugging knob
+    if (forced > 0) return forced;
     int best = 4;
     long best_cost = -1;
     for (int L = 16; L >= 4; --L) {

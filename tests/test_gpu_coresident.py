@@ -1,0 +1,48 @@
+"""GPU: the entry points must give the same (right) answer when another process keeps the same GPU busy, and when the
+library itself runs two row blocks on two streams.  Regression guard for the hazard found at the end of round 1: the
+STFT / iSTFT kernels, built with packed-fp32 (SLP-vectorised) butterflies, returned garbage in whole frames under
+co-residency while being bit-stable alone (csrc/fft.hip, csrc/Makefile)."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def test_results_do_not_depend_on_a_busy_gpu(sd_default):
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    from speechseparation_amd.bsrnn import BSRNN
+    m = BSRNN().eval()
+    m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd_default.items()})
+    m = m.to("cuda")
+    wave = weights.synth_waveform(65, 16 * 1024 + 9, seed=31)
+    w = torch.from_numpy(wave).cuda()
+    x_ref = onp.stft_interleaved(wave[:4])
+    y_ref = onp.separate(sd_default, wave[:4])
+    quiet = {"stft": m.stft(w).cpu().numpy(), "sep": m.separate(w).cpu().numpy()}
+    quiet["istft"] = m.istft(torch.from_numpy(quiet["stft"]).cuda()).cpu().numpy()
+    env = dict(os.environ, PYTHONPATH=REPO)
+    load = subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "coresident_check.py"), "load", "150000"], env=env, cwd=REPO,
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        time.sleep(12)                                   # import + model build of the load process
+        assert load.poll() is None, "the background load ended before the check started"
+        xs = torch.from_numpy(quiet["stft"]).cuda()
+        for _ in range(10):
+            assert np.array_equal(m.stft(w).cpu().numpy(), quiet["stft"])
+            assert np.array_equal(m.istft(xs).cpu().numpy(), quiet["istft"])
+            assert np.array_equal(m.separate(w).cpu().numpy(), quiet["sep"])
+        assert load.poll() is None, "the background load ended during the check"
+    finally:
+        load.kill()
+        load.wait()
+    assert float(np.abs(quiet["stft"][:4] - x_ref).max()) < 1e-4
+    assert float(np.abs(quiet["sep"][:4] - y_ref).max()) < 1e-4

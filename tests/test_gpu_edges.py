@@ -138,3 +138,22 @@ def test_frame_counts_around_the_kernels_chunk_sizes(sd_default, T):
     y1, state = m.forward_chunk(xt[:, :, :cut].contiguous(), state)
     y2, state = m.forward_chunk(xt[:, :, cut:].contiguous(), state)
     assert maxabs(torch.cat([y1, y2], dim=2).cpu().numpy(), y_off.cpu().numpy()) < 2e-5
+
+
+def test_large_batches_equal_their_row_blocks(sd_default):
+    """Rows are independent (bsrnn.py:394-395).  From 128 rows on bsrnn_separate runs two row blocks concurrently on two
+    streams: a 130-row call must equal the same rows separated block by block, bit for bit, run to run, and the oracle on
+    a few rows.  (This check exposed the co-residency hazard of the vectorised FFT kernels, csrc/fft.hip.)"""
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    m = make_model(sd_default)
+    wave = weights.synth_waveform(130, 16 * 1024 + 9, seed=31)
+    w = torch.from_numpy(wave).cuda()
+    whole = m.separate(w).cpu().numpy()
+    halves = np.concatenate([m.separate(w[:65].contiguous()).cpu().numpy(), m.separate(w[65:].contiguous()).cpu().numpy()], 0)
+    assert np.array_equal(whole, halves)
+    for _ in range(5):
+        assert np.array_equal(whole, m.separate(w).cpu().numpy())
+    rows = [0, 64, 65, 129]
+    ref = onp.separate(sd_default, wave[rows])
+    assert maxabs(whole[rows], ref) < TOL
