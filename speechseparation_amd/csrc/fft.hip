@@ -147,7 +147,7 @@ __device__ __forceinline__ void irfft_merge(const float* __restrict__ Y, const S
     irfft_store(r, sc, z, tid);
 }
 
-// NOTE: this file is compiled with -fno-slp-vectorize (csrc/Makefile).  With the SLP vectorizer the complex butterflies
+// NOTE: the library is compiled with -fno-slp-vectorize (csrc/Makefile) because of this file.  With the SLP vectorizer the complex butterflies
 // become packed-fp32 (v_pk_*) code, and the STFT / iSTFT kernels then returned garbage in whole frames whenever kernels of
 // another process or of another stream of this process shared the GPU - always right when alone.  Found with
 // tools/row_block_check.py and tests/coresident_check.py; bisected to the FFT passes (not the barriers, the twiddle loads,
