@@ -1,6 +1,9 @@
 #!/bin/bash
 # Determinism / correctness of the entry points while a second process keeps the GPU busy, then of concurrent row blocks
 # (run on the GPU box: bash tools/coresident.sh).  Never overwrite the .so while a process has it mapped.
+# To reproduce the hazard this guards against, rebuild with the SLP vectorizer first:
+#   touch speechseparation_amd/csrc/fft.hip && make -C speechseparation_amd/csrc EXTRA=-fslp-vectorize
+# (stft / istft / separate then differ from the quiet result in 15-20 of 20 runs, whole frames of garbage; forward stays clean).
 export PYTHONPATH=.
 python tests/coresident_check.py load 400000 > gpurun_out/co_load.txt 2>&1 &
 PL=$!
