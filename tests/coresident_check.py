@@ -1,6 +1,6 @@
 # Which entry point gives run-to-run different results when another process keeps the GPU busy?
 #   PYTHONPATH=. python tests/coresident_check.py load 400000 &   (background load: separate() in a loop)
-#   PYTHONPATH=. python tests/coresident_check.py stft|istft|forward|separate 60
+#   PYTHONPATH=. python tests/coresident_check.py stft|istft|forward|separate|stream|evaluate 60
 # Test infrastructure (imports the oracle to tell which of two differing results is the right one).
 import sys, numpy as np, torch
 from speechseparation_amd import weights
@@ -14,7 +14,15 @@ if kind == "load":
         m.separate(w)
     torch.cuda.synchronize(); print("load done"); sys.exit(0)
 x = m.stft(w)
-fn = {"stft": lambda: m.stft(w), "istft": lambda: m.istft(x), "forward": lambda: m(x), "separate": lambda: m.separate(w)}[kind]
+def stream_run():
+    from speechseparation_amd.bsrnn import StreamingSeparator
+    st = StreamingSeparator(m, channels=2)
+    return torch.cat([st.step(w[:2, i * 1024:(i + 1) * 1024].contiguous()) for i in range(12)], 1)
+def evaluate_run():
+    r = m.evaluate(w[:8], 0.5 * w[:8])
+    return torch.tensor([r[k] for k in sorted(r)], dtype=torch.float64)
+fn = {"stft": lambda: m.stft(w), "istft": lambda: m.istft(x), "forward": lambda: m(x), "separate": lambda: m.separate(w),
+      "stream": stream_run, "evaluate": evaluate_run}[kind]
 ref = fn().cpu().numpy()
 from oracle import bsrnn_numpy as onp
 wn = w.cpu().numpy()
