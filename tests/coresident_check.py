@@ -9,9 +9,13 @@ kind, reps = sys.argv[1], int(sys.argv[2])
 sd = weights.synth_state_dict(None, seed=0)
 m = BSRNN().eval(); m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd.items()}); m = m.to('cuda')
 w = torch.from_numpy(weights.synth_waveform(65, 16 * 1024 + 9, seed=31)).cuda()
-if kind == "load":
+if kind.startswith("load"):          # "load" = separate(); "load:stft" / "load:forward" / "load:dual" = one kernel family only
+    what = kind.partition(":")[2] or "separate"
+    xl = m.stft(w)
+    zl = torch.zeros((65, 17, 12, 64), device="cuda")
+    body = {"separate": lambda: m.separate(w), "stft": lambda: m.stft(w), "forward": lambda: m(xl), "dual": lambda: m.dual_path(zl)}[what]
     for _ in range(reps):
-        m.separate(w)
+        body()
     torch.cuda.synchronize(); print("load done"); sys.exit(0)
 x = m.stft(w)
 def stream_run():
