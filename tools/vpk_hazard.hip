@@ -1,0 +1,91 @@
+// Stand-alone probe for the co-residency hazard of round 1: do packed-fp32 instructions with operand
+// modifiers (the forms the SLP vectorizer emitted for the FFT butterflies) give wrong results while waves of ANOTHER
+// kernel issue MFMAs on the same SIMD?  The victim kernel evaluates chains of v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+// with neg / op_sel modifiers (inline assembly) next to the same arithmetic in scalar instructions and counts lanes where
+// the two disagree; it runs alone, then beside an MFMA-only kernel on a second stream.
+//   hipcc -O3 --offload-arch=gfx950 -o build/vpk_hazard tools/vpk_hazard.hip && ./build/vpk_hazard
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void victim(unsigned long long* bad, int iters, int use_lds)
+{
+    __shared__ v2f buf[2][1024];
+    const int tid = threadIdx.x;
+    v2f a = {1.0f + 0.001f * tid, 0.5f - 0.002f * tid}, b = {0.25f + 0.003f * tid, -0.75f + 0.001f * tid};
+    v2f sa = a, sb = b;                 // scalar twin
+    unsigned long long mism = 0;
+    for (int it = 0; it < iters; ++it) {
+        v2f d, s, m, f;
+        // packed: d = a - b (neg on src1); s = (a.y + b.x, a.x + b.y) via op_sel; m = a * b; f = fma(a, b, -d)
+        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(s) : "v"(a), "v"(b));
+        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(f) : "v"(a), "v"(b), "v"(d));
+        // scalar twins (same IEEE operations)
+        const v2f sd = {sa.x - sb.x, sa.y - sb.y};
+        const v2f ss = {sa.y + sb.x, sa.x + sb.y};
+        const v2f sm = {sa.x * sb.x, sa.y * sb.y};
+        const v2f sf = {__builtin_fmaf(sa.x, sb.x, -sd.x), __builtin_fmaf(sa.y, sb.y, -sd.y)};
+        mism += (d.x != sd.x) + (d.y != sd.y) + (s.x != ss.x) + (s.y != ss.y) + (m.x != sm.x) + (m.y != sm.y) + (f.x != sf.x) + (f.y != sf.y);
+        // next operands: a bounded mix, optionally through LDS like an FFT pass (write, barrier, read a permuted slot)
+        v2f na = {0.5f * (d.x + s.y), 0.5f * (m.x - f.y) + 0.1f}, nb = {0.5f * (s.x - d.y), 0.25f * (f.x + m.y) - 0.2f};
+        if (use_lds) {
+            buf[it & 1][tid] = na; buf[it & 1][tid + 256] = nb;
+            __syncthreads();
+            na = buf[it & 1][(tid * 5 + 1) & 255]; nb = buf[it & 1][256 + ((tid * 3 + 7) & 255)];
+        }
+        a = na; b = nb; sa = na; sb = nb;
+        a.x = __builtin_fminf(__builtin_fmaxf(a.x, -4.f), 4.f); a.y = __builtin_fminf(__builtin_fmaxf(a.y, -4.f), 4.f);
+        b.x = __builtin_fminf(__builtin_fmaxf(b.x, -4.f), 4.f); b.y = __builtin_fminf(__builtin_fmaxf(b.y, -4.f), 4.f);
+        sa = a; sb = b;
+    }
+    if (mism) atomicAdd(bad, mism);
+}
+
+__global__ __launch_bounds__(256) void aggressor(float* sink, int iters)
+{
+    h8 x, y;
+    for (int i = 0; i < 8; ++i) { x[i] = (_Float16)(0.01f * (threadIdx.x + i)); y[i] = (_Float16)(0.02f * (i + 1)); }
+    v16f acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+    for (int it = 0; it < iters; ++it) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, y, acc3, 0, 0, 0);
+    }
+    if (acc0[0] + acc1[1] + acc2[2] + acc3[3] == 12345.f) sink[0] = 1.f;
+}
+
+int main()
+{
+    unsigned long long* d_bad;
+    float* d_sink;
+    CK(hipMalloc(&d_bad, 8)); CK(hipMalloc(&d_sink, 4));
+    hipStream_t sa, sb;
+    CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    for (int use_lds = 0; use_lds < 2; ++use_lds)
+        for (int with_aggr = 0; with_aggr < 2; ++with_aggr) {
+            unsigned long long total = 0;
+            for (int rep = 0; rep < 20; ++rep) {
+                CK(hipMemsetAsync(d_bad, 0, 8, sb));
+                CK(hipStreamSynchronize(sb));
+                if (with_aggr) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), 0, sa, d_sink, 40000);
+                hipLaunchKernelGGL(victim, dim3(2048), dim3(256), 0, sb, d_bad, 20000, use_lds);
+                CK(hipStreamSynchronize(sb)); CK(hipStreamSynchronize(sa));
+                unsigned long long h = 0;
+                CK(hipMemcpy(&h, d_bad, 8, hipMemcpyDeviceToHost));
+                total += h;
+            }
+            printf("victim %s LDS exchange, %s: %llu packed results differ from their scalar twins (20 launches x 2048 x 256 lanes x 20000 x 8)\n",
+                   use_lds ? "with" : "without", with_aggr ? "beside an MFMA kernel" : "alone", total);
+        }
+    return 0;
+}
