@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void victim(unsigned long long* bad, int iters
     v2f a = {1.0f + 0.001f * tid, 0.5f - 0.002f * tid}, b = {0.25f + 0.003f * tid, -0.75f + 0.001f * tid};
     v2f sa = a, sb = b;                 // scalar twin
     unsigned long long mism = 0;
+    const v2f sc = {__builtin_amdgcn_readfirstlane(iters) > 0 ? 0.5f : 0.25f, -0.5f};     // wave-uniform: lives in an SGPR pair
     for (int it = 0; it < iters; ++it) {
         v2f d, s, m, f;
         // packed: d = a - b (neg on src1); s = (a.y + b.x, a.x + b.y) via op_sel; m = a * b; f = fma(a, b, -d)
@@ -29,12 +30,18 @@ __global__ __launch_bounds__(256) void victim(unsigned long long* bad, int iters
         asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(s) : "v"(a), "v"(b));
         asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
         asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(f) : "v"(a), "v"(b), "v"(d));
+        // the vectorised FFT code also feeds packed ops from SGPR pairs (0.5 scale factors) and shuffles halves with v_pk_mov_b32
+        v2f g, h;
+        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(g) : "v"(m), "s"(sc));
+        asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(h) : "v"(g), "v"(f));
+        mism += (g.x != m.x * sc.x) + (g.y != m.y * sc.y) + (h.x != g.y) + (h.y != f.x);
         // scalar twins (same IEEE operations)
         const v2f sd = {sa.x - sb.x, sa.y - sb.y};
         const v2f ss = {sa.y + sb.x, sa.x + sb.y};
         const v2f sm = {sa.x * sb.x, sa.y * sb.y};
         const v2f sf = {__builtin_fmaf(sa.x, sb.x, -sd.x), __builtin_fmaf(sa.y, sb.y, -sd.y)};
         mism += (d.x != sd.x) + (d.y != sd.y) + (s.x != ss.x) + (s.y != ss.y) + (m.x != sm.x) + (m.y != sm.y) + (f.x != sf.x) + (f.y != sf.y);
+        d.x += 0.125f * h.x; s.y -= 0.125f * h.y;           // feed the shuffled values back into the chain
         // next operands: a bounded mix, optionally through LDS like an FFT pass (write, barrier, read a permuted slot)
         v2f na = {0.5f * (d.x + s.y), 0.5f * (m.x - f.y) + 0.1f}, nb = {0.5f * (s.x - d.y), 0.25f * (f.x + m.y) - 0.2f};
         if (use_lds) {
@@ -84,7 +91,7 @@ int main()
                 CK(hipMemcpy(&h, d_bad, 8, hipMemcpyDeviceToHost));
                 total += h;
             }
-            printf("victim %s LDS exchange, %s: %llu packed results differ from their scalar twins (20 launches x 2048 x 256 lanes x 20000 x 8)\n",
+            printf("victim %s LDS exchange, %s: %llu packed results differ from their scalar twins (20 launches x 2048 x 256 lanes x 20000 x 12)\n",
                    use_lds ? "with" : "without", with_aggr ? "beside an MFMA kernel" : "alone", total);
         }
     return 0;
