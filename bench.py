@@ -36,6 +36,13 @@ BYTES_PIPELINE = 96312           # every stage reads its input once, writes its 
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* (f32 in), dense
 DOMINANT = ("bandsplit_mlp", "mask_mlp")
+# what the arithmetic type really is, per BSRNN_GEMM mode (the LSTMs follow BSRNN_LSTM: fp16x2 unless "f32")
+DTYPE_LABEL = {
+    "f32": "f32 (exact fp32 MFMA)",
+    "fp16x2": "f32 io/accumulate, fp16x2-split operands (22-bit operands, 3 f16 MFMA terms; a2*b2 term dropped)",
+    "bf16x3": "f32 io/accumulate, bf16x3-split operands (6 bf16 MFMA terms)",
+    "fp16": "f16 operands, f32 accumulate/io (REDUCED PRECISION configuration)",
+}
 
 
 def exact_macs(v):
@@ -158,6 +165,77 @@ def cpu_baseline(sd, rows, n_samples, budget_s=12.0):
             "seconds_per_pass": med}
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes (one per GPU) and relay
+    rank 0's JSON line.  Runs before this process has made any HIP call (torch.cuda.device_count() does not initialise
+    the runtime on this image); the children are ordinary subprocesses, nothing is exec'ed in place."""
+    import subprocess
+    rehearse = os.environ.get("BSRNN_BENCH_REHEARSE") == "1" or os.environ.get("BSRNN_BENCH_PLUMBING") == "1"
+    if not rehearse:
+        have = torch.cuda.device_count()
+        if n > have:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) visible (BSRNN_BENCH_REHEARSE=1 shares cuda:0 for a rehearsal)" % (n, have))
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.exit("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in bad))
+
+
+def exact_f32_record(args):
+    """The same workload on the library's exact-fp32 kernels (v_mfma_f32_*_f32, bit-exact fp32 fma chains), measured in a
+    child process started before this one touches the GPU (the compute mode is read once per process)."""
+    import subprocess
+    env = dict(os.environ, BSRNN_GEMM="f32", BSRNN_LSTM="f32", BSRNN_BENCH_CHILD="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, args.steps // 2)), "--warmup", str(args.warmup),
+           "--rows", str(args.rows), "--samples", str(args.samples), "--no-cpu-baseline", "--no-exact-f32"]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        return {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "compute": {k: d["compute"][k] for k in ("gemm", "lstm")},
+                "note": "BSRNN_GEMM=f32 BSRNN_LSTM=f32: exact fp32 MFMA kernels of the same library, same workload, separate process"}
+    except Exception as e:      # the sub-record is a report item, not part of `value`
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def plumbing_line(args, world, dist):
+    """BSRNN_BENCH_PLUMBING=1 (CPU test of the launcher and the collectives around the timed region; no kernels run,
+    nothing is measured): rendezvous over gloo, barrier, max-reduce, one JSON line from rank 0."""
+    t = torch.tensor([1.0 + int(os.environ.get("RANK", "0"))], dtype=torch.float64)
+    rccl_ranks = 1
+    if dist is not None:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rccl_ranks = dist.get_world_size()
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"metric": "separated row-frames/sec, batch64 8s@16kHz", "value": None, "unit": "row-frames/s", "n_gpus": world,
+                          "rccl_ranks": rccl_ranks, "backend": "gloo", "steps": args.steps, "warmup": args.warmup, "max_over_ranks": float(t.item()),
+                          "data": "PLUMBING TEST: no kernels run, nothing measured"}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,24 +244,40 @@ def main():
     ap.add_argument("--rows", type=int, default=64, help="rows per GPU")
     ap.add_argument("--samples", type=int, default=128000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-fp32 sub-record (a child process)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with no launcher: become the launcher (N rank processes), before any GPU call
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py start the ranks itself)" % (args.gpus, world))
     dist = None
     # Rehearsal on a one-GPU box (not a measurement): BSRNN_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for
     # the barrier / max-reduce, so the whole multi-rank script path can be exercised without an 8-GPU node.
     rehearse = os.environ.get("BSRNN_BENCH_REHEARSE") == "1"
+    plumbing = os.environ.get("BSRNN_BENCH_PLUMBING") == "1"
     if rehearse:
         local_rank = 0
+    # exact-fp32 sub-record: a child process, run to completion before this process initialises the GPU
+    f32_rec = None
+    if world == 1 and not args.no_exact_f32 and not plumbing:
+        f32_rec = exact_f32_record(args)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
+        if rehearse or plumbing:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if plumbing:
+        plumbing_line(args, world, dist)
+        return
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
@@ -277,9 +371,11 @@ def main():
                 "note": "north-star accounting of the dual-path step: 24576 algorithmic B/row-frame; the step is fp32-compute/latency bound (SURVEY 7.3-1)"}
         line = {
             "metric": "separated row-frames/sec, batch64 8s@16kHz",
-            "value": round(value, 1), "unit": "row-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
+            "value": round(value, 1), "unit": "row-frames/s", "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1, "backend": (dist.get_backend() if dist is not None else "none"),
+            "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if cmode["gemm"] != "fp16" else "f16 (fp32 accumulate)", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks share cuda:0 over gloo; not a measurement)",
+            "dtype": DTYPE_LABEL[cmode["gemm"]], "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks share cuda:0 over gloo; not a measurement)",
             "config": {"workload": "offline separate (STFT->BSRNN.forward->iSTFT), %d rows/GPU x %d samples @16 kHz (T=%d), K=12 bands, fp32"
                                    % (args.rows, args.samples, T),
                        "rows_per_gpu": args.rows, "global_rows": args.rows * world, "frames": T, "parallelism": "dp%d (row shards, no in-path collective)" % world},
@@ -289,6 +385,8 @@ def main():
                                         "f16/bf16 matrix cores unless 'f32' (error at fp32 rounding level, DESIGN.md)"),
             "roofline": roofline, "roofline_dual_path": dual, "stages": fam,
         }
+        if f32_rec is not None:
+            line["exact_f32"] = f32_rec
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(sd, args.rows, args.samples)
             line["cpu_baseline"] = cb

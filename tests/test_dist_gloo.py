@@ -62,3 +62,31 @@ def test_two_rank_gather_matches_unsharded():
     ref = onp.stft_interleaved(weights.synth_waveform(total_rows, n, seed=1234))
     assert np.array_equal(full, ref)
     assert t == 2.0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two rank processes itself (the driver calls it
+    exactly like that).  BSRNN_BENCH_PLUMBING=1: gloo rendezvous, barrier and max-reduce only - no kernels, no GPU."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["BSRNN_BENCH_PLUMBING"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                     # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3
+    assert d["max_over_ranks"] == 2.0                    # rank 1's value won the MAX reduce
+
+
+def test_bench_refuses_a_world_that_contradicts_gpus():
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BSRNN_BENCH_PLUMBING="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
