@@ -40,7 +40,6 @@ DOMINANT = ("bandsplit_mlp", "mask_mlp")
 DTYPE_LABEL = {
     "f32": "f32 (exact fp32 MFMA)",
     "fp16x2": "f32 io/accumulate, fp16x2-split operands (22-bit operands, 3 f16 MFMA terms; a2*b2 term dropped)",
-    "bf16x3": "f32 io/accumulate, bf16x3-split operands (6 bf16 MFMA terms)",
     "fp16": "f16 operands, f32 accumulate/io (REDUCED PRECISION configuration)",
 }
 
@@ -101,8 +100,6 @@ GEMM_LAUNCH_MIX = {
     "f32": (("gemm_f32_kernel<1,", 8), ("gemm_f32_kernel<0,", 1), ("gemm_f32_kernel<3,", 1)),
     "fp16x2": (("gemm_h2_kernel<1, 2,", 6), ("gemm_h2_kernel<1, 1,", 2), ("gemm_h2_kernel<0, 1,", 1), ("gemm_h2_kernel<3, 2,", 1)),
     "fp16": (("gemm_h2_kernel<1, 2, 0, 1>", 6), ("gemm_h2_kernel<1, 1, 0, 1>", 2), ("gemm_h2_kernel<0, 1, 0, 1>", 1), ("gemm_h2_kernel<3, 2, 0, 1>", 1)),
-    "bf16x3": (("gemm_split_kernel<1, 3, 2,", 6), ("gemm_split_kernel<1, 3, 1,", 2), ("gemm_split_kernel<0, 3, 1,", 1),
-               ("gemm_split_kernel<3, 3, 2,", 1)),
 }
 # matrix-pipe roofline of the grouped GEMM per mode: (kernel, peak in algorithmic TFLOP/s, how it is derived)
 GEMM_ROOF = {
@@ -111,7 +108,6 @@ GEMM_ROOF = {
                "(a1b1 + a1b2 + a2b1, fp32 accumulate)"),
     "fp16": ("gemm_h2_kernel<fp16, 1 term>", 2500.0, "f16 MFMA dense peak; REDUCED PRECISION (plain fp16 operands, ~5e-4 relative per product): "
              "not the fp32-accurate default"),
-    "bf16x3": ("gemm_split_kernel<bf16x3>", 2500.0 / 6, "bf16 MFMA dense peak 2500 TFLOP/s / 6 MFMA terms per fp32-accurate product"),
 }
 
 

@@ -15,6 +15,19 @@
  *     and return without synchronising unless stated otherwise;
  *   - return value 0 = success, otherwise a BSRNN_E* code; bsrnn_last_error() gives text;
  *   - nothing here ever falls back to a CPU implementation.
+ *
+ * Concurrency contract
+ *   - ONE call at a time per context.  A context owns one workspace (activations of the call in flight) and one weight
+ *     arena; every compute entry point, bsrnn_commit_params and the stream calls of its bsrnn_stream objects count as
+ *     calls on it.  A call that arrives from a second host thread while another is inside the library is refused with
+ *     BSRNN_ESTATE (it never races).  Use one context per host thread for concurrent work; contexts share nothing.
+ *   - Calls enqueue on the caller's HIP stream.  Consecutive calls on the SAME stream are ordered by the stream.  A call
+ *     on a DIFFERENT stream than the previous call first waits, on the host, for that previous stream to drain (the two
+ *     would otherwise overlap on the workspace): correct, but it serialises - keep a context on one stream.
+ *   - A larger call may regrow the workspace and bsrnn_commit_params rebuilds the arena; both wait for the device first,
+ *     and bsrnn_stream objects notice (a generation counter) and re-capture their hipGraph at their next step.
+ *   - bsrnn_destroy with bsrnn_stream objects still alive only retires the context (further calls: BSRNN_ESTATE); the
+ *     memory is released when the last of its streams is destroyed.
  *   - C = rows of dim 0 (utterance-channels), T / L = STFT frames, F2 = 2050 interleaved
  *     re/im columns, K = number of bands including the zero-width band, H = 64.
  */
@@ -44,22 +57,30 @@ int         bsrnn_abi_version(void);
 const char* bsrnn_last_error(void);
 /* How the matrix products are evaluated, e.g. "gemm=fp16x2 lstm=fp16x2" (measurement / logging only).
  * Inputs, outputs, state and accumulation are float32 in every mode; the modes differ in which matrix pipe
- * carries the products: "f32" = v_mfma_f32_*_f32 (exact fp32 fma chains), "fp16x2" / "bf16x3" = fp32 operands
- * split into 2 fp16 / 3 bf16 pieces and multiplied on the 16-bit matrix cores with fp32 accumulation
+ * carries the products: "f32" = v_mfma_f32_*_f32 (exact fp32 fma chains), "fp16x2" = fp32 operands
+ * split into 2 fp16 pieces and multiplied on the 16-bit matrix cores with fp32 accumulation
  * (error at the level of fp32 rounding noise).  Selected once per process by the environment
- * variables BSRNN_GEMM (f32 | fp16x2 | bf16x3 | fp16) and BSRNN_LSTM (f32 | fp16x2); default fp16x2 for both.
+ * variables BSRNN_GEMM (f32 | fp16x2 | fp16) and BSRNN_LSTM (f32 | fp16x2); default fp16x2 for both.
  * BSRNN_GEMM=fp16 is the one REDUCED-precision mode (plain fp16 operands in the Linear layers, one MFMA term,
  * fp32 accumulation: ~1e-3 of the output range); it exists for the "16-bit compute" benchmark configuration.
  * Range: the fp16x2 mode represents operands up to |a| = 65504 (spectra of audio in [-1, 1] stay below 1024).
- * A larger activation saturates; the kernels notice, and the NEXT call on the context (or bsrnn_sync) fails
- * with BSRNN_ERANGE instead of returning a silently different result.  Rescale the input or use "f32". */
+ * A larger finite activation saturates, and the kernels notice (a host-visible flag).  What happens then:
+ *   - SYNCHRONOUS entry points (bsrnn_evaluate, bsrnn_stream_step_host - they wait for their own kernels) check the flag
+ *     before returning and, if it is set, run the same call again on the library's exact-fp32 kernels (fp32 weights are
+ *     always resident; no range limit) from the same starting state: they return correct numbers with rc 0;
+ *   - ASYNCHRONOUS entry points (everything that takes a stream and returns without waiting) cannot know: the NEXT call
+ *     on the context, bsrnn_sync or bsrnn_stream_get_state fails with BSRNN_ERANGE ("an earlier call ... saturated"),
+ *     once.  The caller then repeats the work after rescaling, or in a process started with BSRNN_GEMM=f32 BSRNN_LSTM=f32.
+ * NaN / Inf inputs are not range errors: they come out as NaN, as they do from the reference. */
 const char* bsrnn_compute_mode(void);
 
 /* ---- construction -------------------------------------------------------------------
  * Replaces `BSRNN()` (bsrnn.py:328-376).  `widths` are band widths in bins, in order,
  * including the trailing zero-width band (generate_bandsplits()[0], bsrnn.py:247-326);
  * sum(widths) must be 1025.  The band table is data: pass a different one for the
- * 41-band variant.  `device` is the HIP device ordinal. */
+ * 41-band variant.  `device` is the HIP device ordinal, or -1 for a HOST-ONLY context: parameter inventory,
+ * bsrnn_set_param / bsrnn_get_param and bsrnn_load_weights_file (as a validator) work without a GPU, every compute
+ * entry point returns BSRNN_ESTATE (tools/convert_weights.py, CPU tests). */
 int  bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx** out);
 void bsrnn_destroy(bsrnn_ctx* ctx);
 int  bsrnn_n_bands(const bsrnn_ctx* ctx);
@@ -77,7 +98,9 @@ int  bsrnn_set_param(bsrnn_ctx* ctx, const char* key, const float* host_data, in
 int  bsrnn_get_param(const bsrnn_ctx* ctx, const char* key, float* host_out, int64_t numel);
 int  bsrnn_commit_params(bsrnn_ctx* ctx);
 /* Flat weight file (speechseparation_amd/weights.py) -- replaces the ONNX file that
- * speech-ladspa-onnx.cpp:73 opens.  Does set_param for every tensor, then commit. */
+ * speech-ladspa-onnx.cpp:73 opens.  Does set_param for every tensor, then commit.  Every tensor must carry a key of
+ * the inventory and exactly its rank and dimensions (BSRNN_ENOKEY / BSRNN_EIO otherwise; sizes are never taken from
+ * the file, and nothing throws across this boundary). */
 int  bsrnn_load_weights_file(bsrnn_ctx* ctx, const char* path);
 
 /* I/O signature of the one-frame model, as the reference's exported ONNX file declares it (infer-streaming.py:74

@@ -98,5 +98,5 @@ def stage_names():
 
 
 def compute_mode():
-    """{'gemm': 'f32'|'fp16x2'|'bf16x3', 'lstm': 'f32'|'fp16x2'} as reported by the library."""
+    """{'gemm': 'f32'|'fp16x2'|'fp16', 'lstm': 'f32'|'fp16x2'} as reported by the library."""
     return dict(kv.split("=") for kv in lib.bsrnn_compute_mode().decode().split())

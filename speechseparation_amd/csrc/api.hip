@@ -7,6 +7,7 @@
 #include "split_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -57,7 +58,16 @@ struct EvRec { hipEvent_t a, b; int stage; };
 }  // namespace
 
 struct bsrnn_ctx {
-    int device = 0;
+    int device = 0;                 // HIP ordinal; -1 = host-only context (parameter staging / file validation, no compute)
+    // Concurrency contract (include/bsrnn_hip.h): one call at a time per context.  `busy` turns an overlapping call from a
+    // second host thread into BSRNN_ESTATE; a call on a different HIP stream than the previous one first waits for that
+    // stream on the host (the context has ONE workspace); `gen` counts reallocations of anything a captured streaming
+    // graph may point at (workspace, tap buffer, weight arena) so that the graph is re-captured instead of replayed.
+    std::atomic<int> busy{0};
+    unsigned gen = 1;
+    int live_streams = 0;           // bsrnn_stream objects that point at this context
+    bool zombie = false;            // bsrnn_destroy() was called while streams were alive: freed with the last stream
+    bool have_last = false;
     std::vector<int> widths, off;   // bins per band, start bin
     int K = 0;
     std::vector<Param> params;
@@ -67,13 +77,17 @@ struct bsrnn_ctx {
     // activation column layout
     std::vector<int> aoff, poff;
     int LDA = 0, LDP = 0;
-    bool slab_flow = false;         // fp16x2 mode: A1 / A2 hold slab-format (pre-split) activations
 
     // device-resident weights and tables
     float* d_arena = nullptr;
     GemmJob* d_jobs = nullptr;
     int2* d_tiles = nullptr;
     int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT], tile_n[NSLOT];
+
+    // fused per-band MLP chains (mlp_chain.hip): device descriptor arrays, grouped by class (kernels.h, ChainLaunch)
+    bool fused = false;             // false: per-layer launches (BSRNN_MLP=layers, fp32 mode, or a band too wide for the LDS image)
+    ChainDesc* d_chain[2] = {nullptr, nullptr};
+    int chain_ncls[2][4];
 
     const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
     const void *bandW16[2][2], *timeW16[2];
@@ -122,6 +136,9 @@ struct bsrnn_stream {
     hipGraph_t graph = nullptr;
     hipStream_t cap = nullptr;
     bool use_graph = true;
+    unsigned gen = 0;                  // context generation the graph was captured against
+    float* shadow = nullptr;           // copy of {buf, prev, state} taken before a synchronous step (range-guard re-run)
+    size_t carry_floats = 0;           // size of that region
 };
 
 namespace {
@@ -275,6 +292,7 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
     float** dst[10] = {&c->Xf, &c->Yf, &c->A1, &c->A2, &c->P, &c->Z0, &c->Z1, &c->HB0, &c->HB1, &c->H1};
     for (int i = 0; i < 10; ++i) { *dst[i] = p; p += sizes[i]; }
     c->cap_rows = rows;
+    ++c->gen;
     return 0;
 }
 int ensure_tap(bsrnn_ctx* c, size_t rows)
@@ -284,6 +302,7 @@ int ensure_tap(bsrnn_ctx* c, size_t rows)
     if (c->d_tap) { HIP_TRY(hipFree(c->d_tap)); c->d_tap = nullptr; }
     HIP_TRY(hipMalloc((void**)&c->d_tap, rows * c->LDP * sizeof(float)));
     c->tap_rows = rows;
+    ++c->gen;
     return 0;
 }
 
@@ -297,15 +316,11 @@ int ensure_streams(bsrnn_ctx* c, int parts)
     return 0;
 }
 
-// xs / ys: the layer's input / output is the slab-format view of X / Y (an A1 / A2 buffer; fp16x2 mode only)
 void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ldy, const float* R, int ldr,
-               const float* Mul, int ldm, float* tap, int M, int epi, hipStream_t s, bool xs = false, bool ys = false)
+               const float* Mul, int ldm, float* tap, int M, int epi, hipStream_t s)
 {
     GemmLaunch g;
     memset(&g, 0, sizeof g);
-    g.out_mode = ys ? 4 : 1;
-    if (xs) { g.Xs = X; g.ldxs = 2 * ldx; }
-    if (ys) { g.Ys = Y; g.ldys = 2 * ldy; }
     g.range_flag = c->d_range;
     g.jobs = c->d_jobs + c->job0[slot];
     g.tiles = c->d_tiles + c->tile0[slot];
@@ -355,14 +370,20 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         break;
     case MS_BANDSPLIT: {   // bandFCs_pre (2 linears) -> residual P; bandFCs (3 linears) -> Z0   bsrnn.py:404-415
         StageScope sc(c, ST_BANDSPLIT, s);
-        // fp16x2 mode: the intermediates A1 / A2 travel pre-split in slab format (sl): written by the producer's
-        // epilogue, copied to LDS by DMA in the consumer (gemm_h2s_kernel)
-        const bool sl = c->slab_flow;
-        gemm_slot(c, PRE0, p.Xf, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, false, sl);
-        gemm_slot(c, PRE2, p.A1, c->LDA, p.P, c->LDP, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, false);
-        gemm_slot(c, FC0, p.P, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, false, sl);
-        gemm_slot(c, FC2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, sl);
-        gemm_slot(c, FC4, p.A2, c->LDA, p.Z0, KH, nullptr, 0, nullptr, 0, nullptr, M, EPI_LINEAR, s, sl, false);
+        if (c->fused && !force_f32()) {      // all five layers of every band in one launch, intermediates in LDS
+            ChainLaunch g;
+            memset(&g, 0, sizeof g);
+            g.desc = c->d_chain[CHAIN_SPLIT];
+            memcpy(g.n_cls, c->chain_ncls[CHAIN_SPLIT], sizeof g.n_cls);
+            g.M = M; g.Xin = p.Xf; g.ldx = c->LDP; g.P = p.P; g.ldp = c->LDP; g.Z = p.Z0; g.ldz = KH; g.range_flag = c->d_range;
+            launch_mlp_chain(g, CHAIN_SPLIT, s);
+            break;
+        }
+        gemm_slot(c, PRE0, p.Xf, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, PRE2, p.A1, c->LDA, p.P, c->LDP, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC0, p.P, c->LDP, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, FC4, p.A2, c->LDA, p.Z0, KH, nullptr, 0, nullptr, 0, nullptr, M, EPI_LINEAR, s);
         break;
     }
     case MS_BAND0: case MS_BAND1: {   // BandwiseLSTM: N = M sequences of length K   bsrnn.py:138-153
@@ -394,12 +415,21 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     }
     case MS_MASK: {   // bandFCs_back (3) + bandFCs_back_post (2) + skip + x*mask   bsrnn.py:420-443
         StageScope sc(c, ST_MASK, s);
-        const bool sl = c->slab_flow;
-        gemm_slot(c, BACK0, p.Z0, KH, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, false, sl);
-        gemm_slot(c, BACK2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, sl);
-        gemm_slot(c, BACK4, p.A2, c->LDA, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, sl);
-        gemm_slot(c, POST0, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s, sl, sl);
-        gemm_slot(c, POST2, p.A2, c->LDA, p.Yf, c->LDP, p.P, c->LDP, p.Xf, c->LDP, p.tap, M, EPI_MASK, s, sl, false);
+        if (c->fused && !force_f32()) {
+            ChainLaunch g;
+            memset(&g, 0, sizeof g);
+            g.desc = c->d_chain[CHAIN_MASK];
+            memcpy(g.n_cls, c->chain_ncls[CHAIN_MASK], sizeof g.n_cls);
+            g.M = M; g.Xin = p.Z0; g.ldx = KH; g.P = p.P; g.ldp = c->LDP; g.Xmul = p.Xf; g.ldm = c->LDP;
+            g.Y = p.Yf; g.ldy = c->LDP; g.tap = p.tap; g.ldt = c->LDP; g.range_flag = c->d_range;
+            launch_mlp_chain(g, CHAIN_MASK, s);
+            break;
+        }
+        gemm_slot(c, BACK0, p.Z0, KH, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, BACK2, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, BACK4, p.A2, c->LDA, p.A1, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, POST0, p.A1, c->LDA, p.A2, c->LDA, nullptr, 0, nullptr, 0, nullptr, M, EPI_LEAKY, s);
+        gemm_slot(c, POST2, p.A2, c->LDA, p.Yf, c->LDP, p.P, c->LDP, p.Xf, c->LDP, p.tap, M, EPI_MASK, s);
         break;
     }
     case MS_ISTFT:
@@ -420,7 +450,6 @@ int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T
     p.state_in = state_in; p.state_out = state_out;
     p.state_slab = (size_t)2 * 2 * C * c->K * HID;     // one Time block's (h,c) x 2 layers
     for (int st = MS_BANDSPLIT; st <= MS_MASK; ++st) run_stage(c, p, st);
-    c->last_stream = s;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -437,10 +466,40 @@ int check_range(bsrnn_ctx* c)
 int check_ready(bsrnn_ctx* c)
 {
     if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0) return fail(BSRNN_ESTATE, "host-only context (device -1): no compute entry points");
+    if (c->zombie) return fail(BSRNN_ESTATE, "context was destroyed");
     if (!c->committed) return fail(BSRNN_ESTATE, "bsrnn_commit_params() has not been called");
     HIP_TRY(hipSetDevice(c->device));
     return check_range(c);
 }
+
+// One call at a time per context: an overlapping call from another host thread is refused instead of racing on the
+// workspace.  (Re-entrant on the same thread: bsrnn_evaluate -> bsrnn_separate, stream_step_host -> stream_step.)
+thread_local bsrnn_ctx* tl_owner = nullptr;
+struct CallGuard {
+    bsrnn_ctx* c; bool ok, outer;
+    explicit CallGuard(bsrnn_ctx* c_) : c(c_), ok(true), outer(false)
+    {
+        if (!c || tl_owner == c) return;
+        int expect = 0;
+        ok = c->busy.compare_exchange_strong(expect, 1);
+        if (ok) { outer = true; tl_owner = c; }
+    }
+    ~CallGuard() { if (outer) { tl_owner = nullptr; c->busy.store(0); } }
+    int refuse() const { return fail(BSRNN_ESTATE, "context is in use by a call from another host thread (one call at a time per context)"); }
+};
+// The context has one workspace: work enqueued by the previous call on ANOTHER stream must have finished before this
+// call's kernels may touch it.  Same stream (the normal case): stream order does it, nothing to do here.
+int order_after_last(bsrnn_ctx* c, hipStream_t s)
+{
+    if (c->have_last && c->last_stream != s) HIP_TRY(hipStreamSynchronize(c->last_stream));
+    c->last_stream = s; c->have_last = true;
+    return 0;
+}
+#define ENTER_CALL(c, s)                                   \
+    CallGuard guard_(c);                                   \
+    if (!guard_.ok) return guard_.refuse();                \
+    { int rc_ = order_after_last(c, s); if (rc_) return rc_; }
 
 }  // namespace
 
@@ -453,7 +512,7 @@ const char* bsrnn_compute_mode(void)
 {
     static char buf[64];
     const int g = gemm_mode(), l = lstm_mode();
-    snprintf(buf, sizeof buf, "gemm=%s lstm=%s", g == GEMM_F32 ? "f32" : (g == GEMM_FP16X2 ? "fp16x2" : (g == GEMM_FP16 ? "fp16" : "bf16x3")),
+    snprintf(buf, sizeof buf, "gemm=%s lstm=%s", g == GEMM_F32 ? "f32" : (g == GEMM_FP16X2 ? "fp16x2" : "fp16"),
              l == LSTM_F32 ? "f32" : "fp16x2");
     return buf;
 }
@@ -467,10 +526,12 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
         sum += widths[i];
     }
     if (sum != NBINS) return fail(BSRNN_EARG, "band widths sum to %d, expected %d", sum, NBINS);
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(BSRNN_EARG, "device %d out of range (%d devices)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    if (device != -1) {
+        int ndev = 0;
+        HIP_TRY(hipGetDeviceCount(&ndev));
+        if (device < 0 || device >= ndev) return fail(BSRNN_EARG, "device %d out of range (%d devices)", device, ndev);
+        HIP_TRY(hipSetDevice(device));
+    }
     bsrnn_ctx* c = new bsrnn_ctx();
     c->device = device;
     c->K = n_bands;
@@ -485,21 +546,16 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
     }
     c->LDA = ao; c->LDP = imax(po, 8);
     build_inventory(c);
+    memset(c->acc_ms, 0, sizeof c->acc_ms);
+    memset(c->acc_n, 0, sizeof c->acc_n);
+    if (device == -1) { *out = c; return 0; }     // host-only: inventory, set / get, weight-file validation
     {   // range-guard word: pinned host memory the fp16x2 kernels can set and the host can read without a sync
         hipError_t e = hipHostMalloc((void**)&c->h_range, sizeof(int), hipHostMallocMapped);
         if (e == hipSuccess) { *c->h_range = 0; e = hipHostGetDevicePointer((void**)&c->d_range, c->h_range, 0); }
         if (e != hipSuccess) { c->h_range = nullptr; c->d_range = nullptr; (void)hipGetLastError(); }
     }
     if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(0, std::min(MAX_PARTS, atoi(e)));
-    {   // BSRNN_GEMM_SLAB=1 (opt-in, fp16x2 mode): the MLP intermediates travel pre-split in slab format and the consuming
-        // layers run on gemm_h2s_kernel (LDS-DMA staging).  Bit-identical results; measured in the pipeline at R = 64:
-        // bandsplit +0.5 %, mask +3 % SLOWER than splitting on the fly (10 % faster on an isolated launch), so it is off.
-        const char* e = getenv("BSRNN_GEMM_SLAB");
-        c->slab_flow = gemm_mode() == GEMM_FP16X2 && e && !strcmp(e, "1");
-    }
     if (const char* e = getenv("BSRNN_PART_LAG")) c->part_lag = std::max(0, std::min((int)MS_COUNT, atoi(e)));
-    memset(c->acc_ms, 0, sizeof c->acc_ms);
-    memset(c->acc_n, 0, sizeof c->acc_n);
 
     // FFT tables in double precision
     std::vector<float> t(2 * 1024 + 2 * 1025 + 2048 + 1024 + 1024 + 16);
@@ -542,9 +598,9 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
     return 0;
 }
 
-void bsrnn_destroy(bsrnn_ctx* c)
+static void destroy_now(bsrnn_ctx* c)
 {
-    if (!c) return;
+    if (c->device < 0) { delete c; return; }
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& r : c->pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -558,10 +614,21 @@ void bsrnn_destroy(bsrnn_ctx* c)
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
+    for (int ch = 0; ch < 2; ++ch)
+        if (c->d_chain[ch]) (void)hipFree(c->d_chain[ch]);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_colmap) (void)hipFree(c->d_colmap);
     if (c->h_range) (void)hipHostFree(c->h_range);
     delete c;
+}
+
+void bsrnn_destroy(bsrnn_ctx* c)
+{
+    if (!c) return;
+    // streams hold a pointer to their context (and a captured graph holds the context's buffers): with streams alive the
+    // context only stops accepting calls here and is freed when the last of them is destroyed
+    if (c->live_streams > 0) { c->zombie = true; return; }
+    destroy_now(c);
 }
 
 int bsrnn_n_bands(const bsrnn_ctx* c) { return c ? c->K : -1; }
@@ -610,25 +677,25 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     if (!c) return fail(BSRNN_EARG, "null context");
     for (const Param& p : c->params)
         if (!p.set) return fail(BSRNN_ESTATE, "missing key '%s'", p.key.c_str());
+    if (c->device < 0) return 0;          // host-only context: the inventory is complete, there is nothing to upload
+    CallGuard guard_(c);
+    if (!guard_.ok) return guard_.refuse();
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
+    ++c->gen;                             // the arena is rebuilt: captured streaming graphs hold pointers into the old one
 
     Arena ar;
     std::vector<GemmJob> jobs;
     std::vector<size_t> jw, jb, jwp;     // arena offsets, patched to pointers after upload
-    // split-precision modes: the same matrix as NP 16-bit planes [NP][N][Kp] (gemm.hip), packed into arena floats
+    // fp16x2 / fp16 modes: the same matrix as two fp16 pieces, slab-interleaved, rows padded to a multiple of 32
+    // (gemm_h2_kernel), packed into arena floats
     const int gmode = gemm_mode();
     auto put_planes = [&](const std::vector<float>& wp, int N, int Kp) -> size_t {
         if (gmode == GEMM_F32 || wp.empty()) return 0;
         std::vector<uint16_t> pl;
-        if (gmode == GEMM_FP16X2 || gmode == GEMM_FP16) {          // slab-interleaved pieces, rows padded to a multiple of 32 (gemm_h2_kernel)
-            const int K32 = (Kp + 31) & ~31, wrow = h2_row_stride(K32);
-            pl.assign((size_t)N * wrow + 1, 0);
-            pack_h2_slabs_host(wp.data(), N, Kp, Kp, K32, wrow, pl.data());
-        } else {
-            pl.assign(wp.size() * gmode + 1, 0);
-            split_planes_host(wp.data(), wp.size(), gmode, pl.data());
-        }
+        const int K32 = (Kp + 31) & ~31, wrow = h2_row_stride(K32);
+        pl.assign((size_t)N * wrow + 1, 0);
+        pack_h2_slabs_host(wp.data(), N, Kp, Kp, K32, wrow, pl.data());
         std::vector<float> packed(pl.size() / 2 + 1);
         memcpy(packed.data(), pl.data(), pl.size() * sizeof(uint16_t));
         return ar.put(packed);
@@ -654,7 +721,6 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         jb.push_back(ar.put(bi.data));
         jwp.push_back(put_planes(wp, N, Kp));
         j.wrow = h2_row_stride((Kp + 31) & ~31);
-        j.xs_off = 2 * x_off; j.ys_off = 2 * y_off;      // slab-format A1 / A2 (used by the slots that run on them, see run_stage)
         jobs.push_back(j);
     };
     auto begin_slot = [&](int slot) { c->job0[slot] = (int)jobs.size(); c->tile0[slot] = (int)tiles.size(); };
@@ -723,6 +789,81 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         snprintf(b, sizeof b, "lstms.%d.m.fc", j);
         add_job(b, H, (j % 2 == 0) ? 2 * H : H, 0, 0, 0, 0);
         end_slot(slot);
+    }
+
+    // fused chains (mlp_chain.hip): per band and chain the five layers' fragment streams, the concatenated biases and a
+    // descriptor; classes by rows per workgroup (the activation image of a row tile must fit 96 KB / RT of LDS)
+    std::vector<ChainDesc> chains[2];
+    std::vector<size_t> ch_w[2], ch_b[2];           // arena offsets, patched to pointers after upload
+    bool fused = gmode != GEMM_F32;
+    if (const char* e = getenv("BSRNN_MLP")) fused = fused && strcmp(e, "layers") != 0;
+    for (int ch = 0; ch < 2 && fused; ++ch) {
+        struct Built { ChainDesc d; size_t w, b; long cost; };
+        std::vector<Built> built;
+        for (int i = 0; i < K && fused; ++i) {
+            const int a = 2 * c->widths[i], m = imax(a, H), pz = imax(a, 2 * H);
+            Built bu;
+            memset(&bu.d, 0, sizeof bu.d);
+            ChainDesc& d = bu.d;
+            d.p_off = c->poff[i]; d.a8 = round8(a); d.z_off = i * H;
+            if (a == 0) {
+                if (ch != CHAIN_SPLIT) continue;
+                snprintf(b, sizeof b, "bandFCs.%d.0.trainable_constant", i);
+                d.constant = 1; d.NW = 8; d.RT = 1; d.nbias = H;
+                bu.w = 0; bu.b = ar.put(P_(c, b).data); bu.cost = -1;
+                built.push_back(bu);
+                continue;
+            }
+            struct LD { const char* fmt; int N, Kd, leaky; };
+            const LD split_l[5] = {{"bandFCs_pre.%d.0", a, a, 1}, {"bandFCs_pre.%d.2", a, a, 1}, {"bandFCs.%d.0", m, a, 1},
+                                   {"bandFCs.%d.2", H, m, 1}, {"bandFCs.%d.4", H, H, 0}};
+            const LD mask_l[5] = {{"bandFCs_back.%d.0", 2 * H, H, 1}, {"bandFCs_back.%d.2", pz, 2 * H, 1}, {"bandFCs_back.%d.4", a, pz, 1},
+                                  {"bandFCs_back_post.%d.0", a, a, 1}, {"bandFCs_back_post.%d.2", a, a, 0}};
+            const LD* ld = ch == CHAIN_SPLIT ? split_l : mask_l;
+            int units = 0, maxntl = 0, nbias = 0;
+            long cost = 0;
+            for (int l = 0; l < CHAIN_LAYERS; ++l) {
+                d.L[l].K16 = (ld[l].Kd + 15) / 16; d.L[l].NTL = (ld[l].N + 31) / 32; d.L[l].leaky = ld[l].leaky;
+                d.L[l].bias_off = nbias; nbias += 32 * d.L[l].NTL;
+                units = imax(units, 2 * d.L[l].K16);
+                if (l + 1 < CHAIN_LAYERS) units = imax(units, 4 * d.L[l].NTL);
+                maxntl = imax(maxntl, d.L[l].NTL);
+                cost += (long)d.L[l].K16 * d.L[l].NTL;
+            }
+            const int img = 2 * units * 512;                                  // bytes of one row tile's image (both pieces)
+            int RT = 4 * img <= CHAIN_LDS_EX ? 4 : (2 * img <= CHAIN_LDS_EX ? 2 : (img <= CHAIN_LDS_EX ? 1 : 0));
+            while (RT >= 1 && (8 / RT) * CHAIN_CT < maxntl) RT /= 2;
+            if (RT < 1 || nbias * 4 > CHAIN_LDS_BIAS) { fused = false; break; }   // a band too wide for the fused kernel: per-layer flow
+            d.RT = RT; d.NW = 8 / RT; d.plane_units = units; d.nbias = nbias;
+            d.in_off = ch == CHAIN_SPLIT ? c->poff[i] : i * H;
+            d.K0 = ch == CHAIN_SPLIT ? round8(a) : H;
+            std::vector<uint16_t> stream;
+            std::vector<float> biases(nbias, 0.f);
+            for (int l = 0; l < CHAIN_LAYERS; ++l) {
+                snprintf(b, sizeof b, ld[l].fmt, i);
+                const Param& w = P_(c, std::string(b) + ".weight");
+                const Param& bi = P_(c, std::string(b) + ".bias");
+                d.L[l].w_off = (unsigned)(stream.size() * sizeof(uint16_t));
+                pack_chain_layer_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, d.NW, gmode == GEMM_FP16 ? 1 : 2, stream);
+                memcpy(&biases[d.L[l].bias_off], bi.data.data(), ld[l].N * sizeof(float));
+            }
+            stream.resize((stream.size() + 7) & ~size_t(7), 0);
+            bu.w = ar.put(reinterpret_cast<const float*>(stream.data()), stream.size() / 2);
+            bu.b = ar.put(biases);
+            bu.cost = cost;
+            built.push_back(bu);
+        }
+        if (!fused) break;
+        // class = rows per workgroup (RT = 1, 2, 4, constant bands), heaviest band first inside a class
+        std::stable_sort(built.begin(), built.end(), [](const Built& x, const Built& y) {
+            const int cx = x.d.constant ? 3 : (x.d.RT == 1 ? 0 : (x.d.RT == 2 ? 1 : 2)), cy = y.d.constant ? 3 : (y.d.RT == 1 ? 0 : (y.d.RT == 2 ? 1 : 2));
+            return cx != cy ? cx < cy : x.cost > y.cost;
+        });
+        memset(c->chain_ncls[ch], 0, sizeof c->chain_ncls[ch]);
+        for (const Built& bu : built) {
+            ++c->chain_ncls[ch][bu.d.constant ? 3 : (bu.d.RT == 1 ? 0 : (bu.d.RT == 2 ? 1 : 2))];
+            chains[ch].push_back(bu.d); ch_w[ch].push_back(bu.w); ch_b[ch].push_back(bu.b);
+        }
     }
 
     // LSTM weights, folded and packed in the kernels' register order (lstm.hip)
@@ -811,6 +952,18 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     HIP_TRY(hipMemcpy(c->d_jobs, jobs.data(), jobs.size() * sizeof(GemmJob), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&c->d_tiles, tiles.size() * sizeof(int2)));
     HIP_TRY(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
+    c->fused = false;
+    for (int ch = 0; ch < 2; ++ch) {
+        if (c->d_chain[ch]) { HIP_TRY(hipFree(c->d_chain[ch])); c->d_chain[ch] = nullptr; }
+        if (!fused) continue;
+        for (size_t i = 0; i < chains[ch].size(); ++i) {
+            chains[ch][i].wstream = c->d_arena + ch_w[ch][i];
+            chains[ch][i].bias = c->d_arena + ch_b[ch][i];
+        }
+        HIP_TRY(hipMalloc((void**)&c->d_chain[ch], chains[ch].size() * sizeof(ChainDesc)));
+        HIP_TRY(hipMemcpy(c->d_chain[ch], chains[ch].data(), chains[ch].size() * sizeof(ChainDesc), hipMemcpyHostToDevice));
+    }
+    c->fused = fused;
     for (int blk = 0; blk < 2; ++blk) {
         for (int layer = 0; layer < 2; ++layer) {
             c->bandW[blk][layer] = c->d_arena + o_bandW[blk][layer];
@@ -831,33 +984,44 @@ int bsrnn_load_weights_file(bsrnn_ctx* c, const char* path)
     FILE* f = fopen(path, "rb");
     if (!f) return fail(BSRNN_EIO, "cannot open %s", path);
     auto bad = [&](const char* why) { fclose(f); return fail(BSRNN_EIO, "%s: %s", path, why); };
-    char magic[8];
-    uint32_t nb = 0, nt = 0;
-    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "BSRNNW01", 8)) return bad("bad magic");
-    if (fread(&nb, 4, 1, f) != 1 || (int)nb != c->K) return bad("band count differs from the context's table");
-    for (uint32_t i = 0; i < nb; ++i) {
-        uint32_t w;
-        if (fread(&w, 4, 1, f) != 1 || (int)w != c->widths[i]) return bad("band table differs from the context's table");
-    }
-    if (fread(&nt, 4, 1, f) != 1) return bad("truncated");
-    std::vector<float> buf;
-    std::string key;
-    for (uint32_t t = 0; t < nt; ++t) {
-        uint32_t kl = 0, nd = 0;
-        if (fread(&kl, 4, 1, f) != 1 || kl > 4096) return bad("bad key length");
-        key.resize(kl);
-        if (kl && fread(&key[0], 1, kl, f) != kl) return bad("truncated key");
-        if (fread(&nd, 4, 1, f) != 1 || nd > 8) return bad("bad ndim");
-        uint64_t n = 1;
-        for (uint32_t d = 0; d < nd; ++d) {
-            uint64_t dim;
-            if (fread(&dim, 8, 1, f) != 1) return bad("truncated dims");
-            n *= dim;
+    // Nothing in the file is trusted: every tensor is looked up in the inventory FIRST and must have exactly the
+    // inventory's rank and dimensions (not just the element count: a transposed matrix has the same count) before a byte
+    // of it is read, so sizes never come from the file; nothing may throw across the C ABI (the LADSPA host would terminate).
+    try {
+        char magic[8];
+        uint32_t nb = 0, nt = 0;
+        if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "BSRNNW01", 8)) return bad("bad magic");
+        if (fread(&nb, 4, 1, f) != 1 || (int)nb != c->K) return bad("band count differs from the context's table");
+        for (uint32_t i = 0; i < nb; ++i) {
+            uint32_t w;
+            if (fread(&w, 4, 1, f) != 1 || (int)w != c->widths[i]) return bad("band table differs from the context's table");
         }
-        buf.resize(n);
-        if (n && fread(buf.data(), 4, n, f) != n) return bad("truncated data");
-        int rc = bsrnn_set_param(c, key.c_str(), buf.data(), (int64_t)n);
-        if (rc) { fclose(f); return rc; }
+        if (fread(&nt, 4, 1, f) != 1) return bad("truncated");
+        if (nt > c->params.size()) return bad("more tensors than the model has parameters");
+        std::vector<float> buf;
+        std::string key;
+        for (uint32_t t = 0; t < nt; ++t) {
+            uint32_t kl = 0, nd = 0;
+            if (fread(&kl, 4, 1, f) != 1 || kl > 256) return bad("bad key length");
+            key.resize(kl);
+            if (kl && fread(&key[0], 1, kl, f) != kl) return bad("truncated key");
+            auto it = c->index.find(key);
+            if (it == c->index.end()) { fclose(f); return fail(BSRNN_ENOKEY, "%s: unexpected key '%s'", path, key.c_str()); }
+            const Param& p = c->params[it->second];
+            if (fread(&nd, 4, 1, f) != 1 || (int)nd != p.ndim) return bad(("rank of '" + key + "' differs from the model's").c_str());
+            uint64_t dims[2] = {0, 0};
+            for (uint32_t d = 0; d < nd; ++d)
+                if (fread(&dims[d], 8, 1, f) != 1) return bad("truncated dims");
+            if (dims[0] != (uint64_t)p.d0 || (nd == 2 && dims[1] != (uint64_t)p.d1))
+                return bad(("shape of '" + key + "' differs from the model's").c_str());
+            const size_t n = (size_t)p.numel();
+            buf.resize(n);
+            if (n && fread(buf.data(), 4, n, f) != n) return bad("truncated data");
+            int rc = bsrnn_set_param(c, key.c_str(), buf.data(), (int64_t)n);
+            if (rc) { fclose(f); return rc; }
+        }
+    } catch (...) {
+        return bad("out of memory or malformed file");
     }
     fclose(f);
     return bsrnn_commit_params(c);
@@ -883,6 +1047,7 @@ int bsrnn_forward(bsrnn_ctx* c, const float* x, float* y, float* mask, int32_t C
     if (rc) return rc;
     if (!x || !y || C < 1 || T < 1) return fail(BSRNN_EARG, "bsrnn_forward: bad arguments (C=%d, T=%d)", C, T);
     hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
     const size_t M = (size_t)C * T;
     if ((rc = ensure_ws(c, M))) return rc;
     if (mask && (rc = ensure_tap(c, M))) return rc;
@@ -904,6 +1069,7 @@ int bsrnn_forward_chunk(bsrnn_ctx* c, const float* x, const float* state_in, flo
     if (rc) return rc;
     if (!x || !y || !state_in || !state_out || C < 1 || L < 1) return fail(BSRNN_EARG, "bsrnn_forward_chunk: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
     const size_t M = (size_t)C * L;
     if ((rc = ensure_ws(c, M))) return rc;
     { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, L, s); }
@@ -926,6 +1092,7 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
     if (rc) return rc;
     if (!z || !z_out || C < 1 || T < 1) return fail(BSRNN_EARG, "bsrnn_dual_path: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
     const int M = C * T, K = c->K;
     if ((rc = ensure_ws(c, M))) return rc;
     const size_t nz = (size_t)M * K * HID;
@@ -948,9 +1115,11 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
 int bsrnn_stft(bsrnn_ctx* c, const float* wave, float* x, int32_t R, int64_t n, void* stream)
 {
     if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
     HIP_TRY(hipSetDevice(c->device));
     if (!wave || !x || R < 1 || n <= NFFT / 2) return fail(BSRNN_EARG, "bsrnn_stft: need n > 1024 samples (reflect padding), got %lld", (long long)n);
     hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
     const int T = 1 + (int)(n / HOPS);
     int rc = ensure_ws(c, (size_t)R * T);
     if (rc) return rc;
@@ -963,9 +1132,11 @@ int bsrnn_stft(bsrnn_ctx* c, const float* wave, float* x, int32_t R, int64_t n, 
 int bsrnn_istft(bsrnn_ctx* c, const float* y, float* wave_out, int32_t R, int32_t T, void* stream)
 {
     if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
     HIP_TRY(hipSetDevice(c->device));
     if (!y || !wave_out || R < 1 || T < 2) return fail(BSRNN_EARG, "bsrnn_istft: need T >= 2 frames");
     hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
     int rc = ensure_ws(c, (size_t)R * T);
     if (rc) return rc;
     { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, y, c->Yf, R, T, s); }
@@ -983,6 +1154,7 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
     if (rc) return rc;
     if (!wave || !wave_out || R < 1 || n <= NFFT / 2) return fail(BSRNN_EARG, "bsrnn_separate: need n > 1024 samples, got %lld", (long long)n);
     hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
     const int T = 1 + (int)(n / HOPS);
     if ((rc = ensure_ws(c, (size_t)R * T))) return rc;
     const int64_t out_len = (int64_t)(T - 1) * HOPS;
@@ -1016,7 +1188,6 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
             HIP_TRY(hipEventRecord(c->ev_join[j], c->aux[j]));
             HIP_TRY(hipStreamWaitEvent(s, c->ev_join[j], 0));
         }
-    c->last_stream = s;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1042,27 +1213,29 @@ int bsrnn_evaluate(bsrnn_ctx* c, const float* mix, const float* speech, int32_t 
     if ((rc = check_ready(c))) return rc;
     if (!mix || R < 1 || n <= NFFT / 2) return fail(BSRNN_EARG, "bsrnn_evaluate: need n > 1024 samples, got %lld", (long long)n);
     hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
     if (!est_out && hipMalloc((void**)&est, (size_t)R * n_est * sizeof(float)) != hipSuccess) {
         est = nullptr;
         return fail(BSRNN_EHIP, "bsrnn_evaluate: out of device memory");
     }
+    auto run = [&]() -> int {
     // x_time and the estimate's spectrum (left in Yf, frame-major)                               m_dataset.py:186-195
-    if ((rc = bsrnn_separate(c, mix, est, R, n, stream))) return cleanup(rc);
+    if ((rc = bsrnn_separate(c, mix, est, R, n, stream))) return rc;
     // waveform_speech_freq: the clean signal through the same analysis (Xf is free once the mask launch ran)   :196
     launch_stft(c->tb, speech, c->Xf, R, n, T, s);
 
     const int chunks = metric_time_chunks(n_est), FB = 512, IB = 256;
     const size_t n_time = (size_t)R * chunks * METRIC_TIME_Q, n_si = (size_t)R * chunks * 2, n_freq = (size_t)FB * 2, n_in = IB;
     const size_t n_part = n_time + n_si + n_freq + n_in;
-    if (hipMalloc((void**)&d_part, n_part * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_alpha, R * sizeof(float)) != hipSuccess)
-        return cleanup(fail(BSRNN_EHIP, "bsrnn_evaluate: out of device memory"));
+    if ((!d_part && hipMalloc((void**)&d_part, n_part * sizeof(double)) != hipSuccess) || (!d_alpha && hipMalloc((void**)&d_alpha, R * sizeof(float)) != hipSuccess))
+        return fail(BSRNN_EHIP, "bsrnn_evaluate: out of device memory");
     double *p_time = d_part, *p_si = p_time + n_time, *p_freq = p_si + n_si, *p_in = p_freq + n_freq;
     launch_metric_time(est, speech, mix, R, n_est, n, p_time, s);
     launch_metric_freq(c->tb, c->Yf, c->Xf, R * T, p_freq, FB, s);
     launch_metric_input_sdr(speech, mix, R, n, p_in, IB, s);
     std::vector<double> h(n_part);
     if (hipMemcpyAsync(h.data(), d_part, (n_time) * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-        return cleanup(fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError())));
+        return fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError()));
     std::vector<double> q((size_t)R * METRIC_TIME_Q, 0.0);
     for (int r = 0; r < R; ++r)
         for (int ch = 0; ch < chunks; ++ch)
@@ -1072,11 +1245,11 @@ int bsrnn_evaluate(bsrnn_ctx* c, const float* mix, const float* speech, int32_t 
     std::vector<float> alpha(R);
     for (int r = 0; r < R; ++r) alpha[r] = ((float)q[(size_t)r * METRIC_TIME_Q + 2] + eps) / ((float)q[(size_t)r * METRIC_TIME_Q + 0] + eps);
     if (hipMemcpyAsync(d_alpha, alpha.data(), R * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess)
-        return cleanup(fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError())));
+        return fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError()));
     launch_metric_sisdr(est, speech, d_alpha, R, n_est, n, p_si, s);
     if (hipMemcpyAsync(h.data() + n_time, p_si, (n_si + n_freq + n_in) * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
-        return cleanup(fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError())));
+        return fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(hipGetLastError()));
 
     double sdr = 0, sisdr = 0, l1_time = 0, m2 = 0, md2 = 0;
     for (int r = 0; r < R; ++r) {
@@ -1102,29 +1275,54 @@ int bsrnn_evaluate(bsrnn_ctx* c, const float* mix, const float* speech, int32_t 
     metrics[BSRNN_M_L1_IM] = l1_im;
     metrics[BSRNN_M_SEPARATION_DB] = 10.0 * log(m2 / md2);                                     // natural log, infer.py:47
     const hipError_t e = hipGetLastError();
-    return cleanup(e == hipSuccess ? 0 : fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(e)));
+    return e == hipSuccess ? 0 : fail(BSRNN_EHIP, "bsrnn_evaluate: %s", hipGetErrorString(e));
+    };
+    rc = run();
+    // Synchronous entry point: every kernel of the call has finished, so the range guard of the fp16x2 kernels is final.
+    // If an operand left the fp16 range, the numbers above are saturated: run the call again on the exact-fp32 kernels of
+    // this library (same weights, no range limit) instead of returning them.
+    if (rc == 0 && c->h_range && *(volatile int*)c->h_range && !force_f32()) {
+        *(volatile int*)c->h_range = 0;
+        set_force_f32(true);
+        rc = run();
+        set_force_f32(false);
+    }
+    return cleanup(rc);
 }
 
+
 // --------------------------------------------------------------------------- streaming
+// Device layout of a stream object: [buf | prev | state] (everything a step carries to the next one, contiguous so that
+// one copy snapshots it), its shadow, then the per-step scratch [X | Y | chunk | out | mix].
+static size_t stream_carry_floats(const bsrnn_ctx* c, int C) { return (size_t)C * NFFT * 2 + (size_t)4 * 2 * C * c->K * HID; }
+static size_t stream_total_floats(const bsrnn_ctx* c, int C)
+{
+    return 2 * stream_carry_floats(c, C) + (size_t)C * ((size_t)c->LDP * 2 + HOPS * 2) + 4;
+}
+
 int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
 {
     int rc = check_ready(c);
     if (rc) return rc;
     if (!out || C < 1) return fail(BSRNN_EARG, "bsrnn_stream_create: bad arguments");
+    CallGuard guard_(c);
+    if (!guard_.ok) return guard_.refuse();
     bsrnn_stream* st = new bsrnn_stream();
     st->ctx = c; st->C = C;
     const size_t nstate = (size_t)4 * 2 * C * c->K * HID;
-    const size_t total = (size_t)C * (NFFT * 2 + (size_t)c->LDP * 2 + HOPS * 2) + nstate + 4;
+    const size_t total = stream_total_floats(c, C);
+    st->carry_floats = stream_carry_floats(c, C);
     float* p = nullptr;
     hipError_t e = hipMalloc((void**)&p, total * sizeof(float));
     if (e != hipSuccess) { delete st; return fail(BSRNN_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
     st->buf = p; p += (size_t)C * NFFT;
     st->prev = p; p += (size_t)C * NFFT;
+    st->state = p; p += nstate;
+    st->shadow = p; p += st->carry_floats;
     st->X = p; p += (size_t)C * c->LDP;
     st->Y = p; p += (size_t)C * c->LDP;
     st->chunk = p; p += (size_t)C * HOPS;
     st->out = p; p += (size_t)C * HOPS;
-    st->state = p; p += nstate;
     st->mixp = p;
     st->use_graph = getenv("BSRNN_NO_GRAPH") == nullptr;
     if (hipHostMalloc((void**)&st->h_in, (size_t)C * HOPS * sizeof(float), hipHostMallocDefault) != hipSuccess ||
@@ -1135,6 +1333,7 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     if (e != hipSuccess) { (void)hipFree(st->buf); delete st; return fail(BSRNN_EHIP, "hipMemset: %s", hipGetErrorString(e)); }
     rc = ensure_ws(c, C);
     if (rc) { (void)hipFree(st->buf); delete st; return rc; }
+    ++c->live_streams;
     *out = st;
     return 0;
 }
@@ -1142,7 +1341,8 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
 void bsrnn_stream_destroy(bsrnn_stream* st)
 {
     if (!st) return;
-    (void)hipSetDevice(st->ctx->device);
+    bsrnn_ctx* c = st->ctx;
+    (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (st->exec) (void)hipGraphExecDestroy(st->exec);
     if (st->graph) (void)hipGraphDestroy(st->graph);
@@ -1151,15 +1351,14 @@ void bsrnn_stream_destroy(bsrnn_stream* st)
     if (st->h_out) (void)hipHostFree(st->h_out);
     (void)hipFree(st->buf);
     delete st;
+    if (--c->live_streams == 0 && c->zombie) destroy_now(c);     // bsrnn_destroy() came first: the context goes with its last stream
 }
 
 int bsrnn_stream_reset(bsrnn_stream* st, void* stream)
 {
     if (!st) return fail(BSRNN_EARG, "null stream");
     HIP_TRY(hipSetDevice(st->ctx->device));
-    const size_t nstate = (size_t)4 * 2 * st->C * st->ctx->K * HID;
-    const size_t total = (size_t)st->C * (NFFT * 2 + (size_t)st->ctx->LDP * 2 + HOPS * 2) + nstate + 4;
-    HIP_TRY(hipMemsetAsync(st->buf, 0, total * sizeof(float), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(st->buf, 0, stream_total_floats(st->ctx, st->C) * sizeof(float), (hipStream_t)stream));
     return 0;
 }
 
@@ -1174,6 +1373,12 @@ static int stream_step_launches(bsrnn_stream* st, hipStream_t s)
     return 0;
 }
 
+static void stream_drop_graph(bsrnn_stream* st)
+{
+    if (st->exec) { (void)hipGraphExecDestroy(st->exec); st->exec = nullptr; }
+    if (st->graph) { (void)hipGraphDestroy(st->graph); st->graph = nullptr; }
+}
+
 int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mix, void* stream)
 {
     if (!st || !chunk || !out) return fail(BSRNN_EARG, "bsrnn_stream_step: null argument");
@@ -1181,13 +1386,22 @@ int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mi
     int rc = check_ready(c);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    if ((rc = ensure_ws(c, st->C))) return rc;
     const size_t nb = (size_t)st->C * HOPS * sizeof(float);
     if (chunk != st->chunk) HIP_TRY(hipMemcpyAsync(st->chunk, chunk, nb, hipMemcpyDeviceToDevice, s));
     int mix_bits;
     memcpy(&mix_bits, &mix, sizeof mix_bits);
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)st->mixp, mix_bits, 1, s));
-    if (st->use_graph && c->prof == 0) {
-        if (!st->exec) {      // capture once: every pointer inside the step belongs to the stream object / context
+    if (st->use_graph && c->prof == 0 && !force_f32()) {
+        // The captured step holds the context's workspace and weight-arena pointers.  A larger call on the context (workspace
+        // regrown) or a re-commit of the parameters (arena rebuilt) since the capture changes ctx->gen: capture again
+        // instead of replaying launches that point into freed memory.
+        if (st->exec && st->gen != c->gen) {
+            HIP_TRY(hipDeviceSynchronize());
+            stream_drop_graph(st);
+        }
+        if (!st->exec) {
             if (!st->cap) HIP_TRY(hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking));
             HIP_TRY(hipStreamBeginCapture(st->cap, hipStreamCaptureModeThreadLocal));
             rc = stream_step_launches(st, st->cap);
@@ -1195,6 +1409,7 @@ int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mi
             if (rc) return rc;
             if (e != hipSuccess) return fail(BSRNN_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
             HIP_TRY(hipGraphInstantiate(&st->exec, st->graph, nullptr, nullptr, 0));
+            st->gen = c->gen;
         }
         HIP_TRY(hipGraphLaunch(st->exec, s));
     } else if ((rc = stream_step_launches(st, s))) {
@@ -1208,14 +1423,31 @@ int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mi
 int bsrnn_stream_step_host(bsrnn_stream* st, const float* chunk_host, float* out_host, float mix)
 {
     if (!st || !chunk_host || !out_host) return fail(BSRNN_EARG, "bsrnn_stream_step_host: null argument");
-    HIP_TRY(hipSetDevice(st->ctx->device));
+    bsrnn_ctx* c = st->ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    ENTER_CALL(c, (hipStream_t) nullptr);
     const size_t nb = (size_t)st->C * HOPS * sizeof(float);
     memcpy(st->h_in, chunk_host, nb);
     HIP_TRY(hipMemcpyAsync(st->chunk, st->h_in, nb, hipMemcpyHostToDevice, nullptr));
-    int rc = bsrnn_stream_step(st, st->chunk, st->out, mix, nullptr);
-    if (rc) return rc;
+    // split-precision modes: keep what the step is about to overwrite (analysis buffer, previous synthesis frame, LSTM
+    // state), so that a step whose operands leave the fp16 range can be run again, exactly, from the same starting point
+    const bool guarded = c->h_range && (gemm_mode() != GEMM_F32 || lstm_mode() != LSTM_F32);
+    if (guarded) HIP_TRY(hipMemcpyAsync(st->shadow, st->buf, st->carry_floats * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    if ((rc = bsrnn_stream_step(st, st->chunk, st->out, mix, nullptr))) return rc;
     HIP_TRY(hipMemcpyAsync(st->h_out, st->out, nb, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
+    if (guarded && *(volatile int*)c->h_range) {
+        // synchronous call: the guard is final.  Re-run this step on the exact-fp32 kernels of the library (no range limit).
+        *(volatile int*)c->h_range = 0;
+        HIP_TRY(hipMemcpyAsync(st->buf, st->shadow, st->carry_floats * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+        set_force_f32(true);
+        rc = bsrnn_stream_step(st, st->chunk, st->out, mix, nullptr);
+        set_force_f32(false);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(st->h_out, st->out, nb, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     memcpy(out_host, st->h_out, nb);
     return 0;
 }
@@ -1227,7 +1459,7 @@ int bsrnn_stream_get_state(bsrnn_stream* st, float* state_host)
     HIP_TRY(hipDeviceSynchronize());
     const size_t nstate = (size_t)4 * 2 * st->C * st->ctx->K * HID;
     HIP_TRY(hipMemcpy(state_host, st->state, nstate * sizeof(float), hipMemcpyDeviceToHost));
-    return 0;
+    return check_range(st->ctx);          // asynchronous steps report a range violation here (or at the next call / bsrnn_sync)
 }
 
 // --------------------------------------------------------------------------- measurement

@@ -4,14 +4,15 @@
 // fc of NormRNNResidual :84) with one launch per "layer slot": a table of (band job, column
 // tile) x 128-row tiles of the M = C*T frame rows, walked in an XCD-aware order.
 //
-// Three kernels, selected by launch_gemm() from BSRNN_GEMM (kernels.h, GemmMode):
+// Two kernels, selected by launch_gemm() from BSRNN_GEMM (kernels.h, GemmMode):
 //   gemm_h2_kernel     (default, "fp16x2"; TERMS = 1: "fp16")  fp32 operands as two fp16 pieces, three MFMA terms on
 //                      v_mfma_f32_32x32x16_f16 with fp32 accumulation - fp32-level accuracy at 3/16 of the fp32
 //                      matrix-pipe time; pipelined main loop (two LDS stages, one barrier per slab);
-//   gemm_split_kernel  ("bf16x3", and the measurement variants of tools/gemm_planes_bench.hip)  generic split-
-//                      precision kernel: 2 fp16 or 3 bf16 pieces, operands split on the fly or pre-split planes;
-//   gemm_f32_kernel    ("f32")  exact fp32 on v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (no xf32 on gfx950).
-// All share the job / tile tables, the XCD mapping, the band-padded layouts (every segment 32-byte aligned, pad
+//   gemm_f32_kernel    ("f32", and the re-run of a call whose operands left the fp16x2 range)  exact fp32 on
+//                      v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (no xf32 on gfx950).
+// (The per-band MLP chains themselves run fused, one workgroup per (band, row tile): mlp_chain.hip; these per-layer
+// launches carry the residual fc of the dual-path blocks, the unfused A/B flow BSRNN_MLP=layers and the fp32 mode.)
+// Both share the job / tile tables, the XCD mapping, the band-padded layouts (every segment 32-byte aligned, pad
 // columns zero) and the LDS-staged 16-byte epilogue with the fused bias / LeakyReLU / residual / mask variants.
 //
 // gemm_f32_kernel: tile 128 x (64*NT) x BK per 256-thread workgroup, four waves as 2(M) x 2(N), each wave a
@@ -275,54 +276,19 @@ __global__ __launch_bounds__(256, (NT == 1 ? GEMM_OCC64 : 2)) void gemm_f32_kern
     }
 }
 
-// =====================================================================================
-// Split-precision kernel.  fp32 operands are represented as NP low-precision pieces and the product is evaluated
-// on the 16-bit matrix cores (16x the MACs per cycle of v_mfma_f32_32x32x2_f32) with fp32 accumulation:
-//   NP = 3 (bf16x3): a = a1 + a2 + a3 exactly (8 significant bits each, the residuals are exact in fp32); the six
-//          terms of weight >= 2^-16, a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2); the dropped ones are <= 2^-24.
-//   NP = 2 (fp16x2): a ~ a1 + 2^-11 a2 with a1 = fp16(a), a2 = fp16(2^11 (a - a1)) - 22 significant bits, i.e.
-//          2^-23 relative representation error per operand, the level of fp32 accumulation noise.  Three MFMA
-//          terms: hi += a1 b1;  lo += a1 b2 + a2 b1;  result = hi + 2^-11 lo  (a2 b2 ~ 2^-22 is dropped).
-//          The 2^11 scaling keeps a2 out of the fp16 subnormal range for |a| >= 2^-14; |a| is clamped to the
-//          fp16 maximum 65504 (the model's activations and weights are O(1); a value beyond that would saturate).
-//          (Scheme: Ootomo & Yokota, "Recovering single precision accuracy from Tensor Cores...", 2022.)
-// Same XCD-aware work mapping and LDS-staged epilogue as the fp32 kernel; the pieces sit in LDS as NP planes
-// with 80-byte rows (conflict-free ds_read_b128 fragments).  Measured limits (tools/gemm_planes_bench.hip) are the
-// CU's global-load path and the per-slab barrier pairs, not the MFMA pipe, hence:
-//   * NT = 2: 128 x 128 tile, four waves of 64 x 64;
-//   * BMODE 1: weights arrive already split (GemmJob::Wp, NP planes made once on the host);  0: split on the fly;
-//   * AMODE 1: activations arrive as NP planes too (written by the producing layer's epilogue, out_mode & 2);
-//     0: fp32 activations are split by the staging threads;
-//   * ACC2: separate accumulators for the leading term and the corrections (required for NP = 2);
-//   * PF: slabs in flight (register staging sets).
-// ABL (measurement only): 1 = no global loads after the first slab, 2 = no MFMA, 4 = epilogue without its global
-// stores, 8 = no epilogue at all (one store per wave keeps the accumulators alive).
-// =====================================================================================
+// fp16x2 split of an fp32 value: a ~ a1 + 2^-11 a2 with a1 = fp16(a), a2 = fp16(2^11 (a - a1)) - 22 significant bits, i.e. 2^-23
+// relative representation error per operand, the level of fp32 accumulation noise.  Three MFMA terms:
+// hi += a1 b1;  lo += a1 b2 + a2 b1;  result = hi + 2^-11 lo  (a2 b2 ~ 2^-22 is dropped).  The 2^11 scaling keeps a2 out of the
+// fp16 subnormal range for |a| >= 2^-14.  (Scheme: Ootomo & Yokota, "Recovering single precision accuracy from Tensor
+// Cores...", 2022; here the correction terms get their own accumulator.)
 template <int NP> struct Piece;
-template <> struct Piece<3> {
-    typedef __bf16 T;
-    typedef __bf16 T4 __attribute__((ext_vector_type(4)));
-    typedef __bf16 T8 __attribute__((ext_vector_type(8)));
-    static __device__ __forceinline__ void split(const v4f a, T4* p)
-    {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            p[0][i] = (__bf16)a[i];
-            const float r1 = a[i] - (float)p[0][i];
-            p[1][i] = (__bf16)r1;
-            p[2][i] = (__bf16)(r1 - (float)p[1][i]);
-        }
-    }
-    static __device__ __forceinline__ v16f mfma(const T8 a, const T8 b, const v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-};
 template <> struct Piece<2> {
     typedef _Float16 T;
     typedef _Float16 T4 __attribute__((ext_vector_type(4)));
     typedef _Float16 T8 __attribute__((ext_vector_type(8)));
-    // a1 = fp16(a) (RNE); a2 = fp16(2048 (a - a1)): a - a1 and the scaling are exact in fp32, so the fused form
-    // fma(-a1, 2048, 2048 a) rounds once, to the same value - two VALU instructions per element (v_pk_mul_f32 +
-    // v_fma_mix{lo,hi}_f16) instead of convert-back / subtract / multiply / convert.  |a| > 65504 makes a1
-    // infinite: callers track max |a| and raise the range flag (the result is invalid either way).
+    // a - a1 and the scaling are exact in fp32, so the fused form fma(-a1, 2048, 2048 a) rounds once, to the same value as
+    // convert-back / subtract / multiply / convert - two VALU instructions per element (v_pk_mul_f32 + v_fma_mix{lo,hi}_f16).
+    // |a| > 65504 makes a1 infinite: callers track max |a| and raise the range flag (the result is invalid either way).
     static __device__ __forceinline__ void split(const v4f a, T4* p)
     {
 #pragma unroll
@@ -330,371 +296,13 @@ template <> struct Piece<2> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[1][i] = (_Float16)__builtin_fmaf(-(float)p[0][i], 2048.f, a[i] * 2048.f);
     }
-    static __device__ __forceinline__ v16f mfma(const T8 a, const T8 b, const v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-template <int EPI, int NP, int NT, int AMODE, int BMODE, int ACC2, int PF = 1, int ABL = 0, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : (NT == 1 ? 3 : 2))) void gemm_split_kernel(GemmLaunch g)
-{
-    static_assert(NP == 3 || ACC2 == 1, "fp16x2 keeps the scaled corrections in their own accumulator");
-    static_assert(NW == 4 || (NW == 8 && NT == 2), "waves: 2 x 2 (each 64 x 32 NT), or 2 x 4 on the 128-wide tile (each 64 x 32)");
-    constexpr int TT = 64 * NW, WN = NW / 2, NJ = 2 * NT / WN;     // threads, waves along N, 32-column tiles per wave
-    constexpr int RP = TT / 4, RS = TT / 8;                       // rows per staging pass: 16-bit planes / fp32
-    constexpr int APP = BM / RP, BPP = 64 * NT / RP, ASP = BM / RS, BSP = 64 * NT / RS;
-    typedef Piece<NP> PC;
-    typedef typename PC::T hT;
-    typedef typename PC::T4 h4;
-    typedef typename PC::T8 h8;
-    typedef const h8 __attribute__((address_space(1)))* gch8;
-    typedef h8 __attribute__((address_space(1)))* gh8;
-    typedef const hT __attribute__((address_space(1)))* gch;
-    constexpr int BN = 64 * NT;
-    constexpr int PS = 40;                          // plane row stride in 16-bit elements (80 bytes: 64 data + 16 pad)
-    constexpr int PLANE = (BM + BN) * PS;           // one plane: A rows then B rows
-    constexpr int ES = BN + 4;                      // epilogue staging row stride (floats)
-    constexpr int NACC = ACC2 ? 2 : 1;
-    typedef const v4f __attribute__((address_space(1)))* gcf4;
-    __shared__ __attribute__((aligned(16))) hT smemh[(NP * PLANE * 2 >= 64 * ES * 4) ? NP * PLANE : 64 * ES * 2];
-
-    const int m_tiles = (g.M + BM - 1) / BM;
-    const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
-    const int mchunk = g.mchunk;
-    const int per_chunk = mchunk * g.n_tiles;
-    const int chunk = (lidx / per_chunk) * 8 + xcd;
-    const int rem = lidx % per_chunk;
-    const int m_tile = chunk * mchunk + rem % mchunk;
-    if (m_tile >= m_tiles) return;
-    const int2 tj = g.tiles[rem / mchunk];
-    const GemmJob job = g.jobs[tj.x];
-    const int n0 = tj.y * BN;
-    const int m0 = m_tile * BM;
-    const int N = job.N, K = job.K, M = g.M;       // K is a multiple of 8 (zero-padded weights, zero pad columns)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int half = lane >> 5, r32 = lane & 31;
-    const int wcol = 32 * NJ * wn;                 // first column of this wave inside the tile
-    float bias[NJ];
-    bool live[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int nc = n0 + wcol + 32 * j + r32;
-        bias[j] = ((gcf)job.bias)[nc < N ? nc : N - 1];
-        live[j] = (n0 + wcol + 32 * j) < N;
-    }
-
-    // staging in 16-byte units.  16-bit planes: 4 units per 32-deep row, 64 rows per pass of the 256 threads;
-    // fp32: 8 units per row, 32 rows per pass.
-    const int p_row = tid >> 2, p_k = (tid & 3) * 8;
-    const int s_row = tid >> 3, s_k = (tid & 7) * 4;
-    const gch Wp = (gch)job.Wp;
-    const unsigned wplane = (unsigned)N * (unsigned)K;
-    const gcf W = (gcf)job.W;
-    const gch Xp = (gch)g.Xp + job.x_off;
-    const gcf X = (gcf)(g.X + job.x_off);
-    unsigned oap[APP], oa[ASP], obp[BPP], ob[BSP];
-    // register staging sets: PF slabs are in flight (the loads of slab k + PF are issued before the MFMAs of slab k)
-    struct Stage { v4f ra[ASP]; v4f rb[BSP]; h8 rap[APP][NP]; h8 rbp[BPP][NP]; };
-    Stage st[PF];
-    if (AMODE == 1) {
-#pragma unroll
-        for (int i = 0; i < APP; ++i) { int row = m0 + p_row + RP * i; row = row < M ? row : M - 1; oap[i] = (unsigned)row * (unsigned)g.ldx + p_k; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < ASP; ++i) { int row = m0 + s_row + RS * i; row = row < M ? row : M - 1; oa[i] = (unsigned)row * (unsigned)g.ldx + s_k; }
-    }
-    if (BMODE == 1) {
-#pragma unroll
-        for (int i = 0; i < BPP; ++i) { int row = n0 + p_row + RP * i; row = row < N ? row : N - 1; obp[i] = (unsigned)row * (unsigned)K + p_k; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < BSP; ++i) { int row = n0 + s_row + RS * i; row = row < N ? row : N - 1; ob[i] = (unsigned)row * (unsigned)K + s_k; }
-    }
-    // full slabs take plain loads: any arithmetic on the loaded registers here (tail masking) would make the
-    // compiler wait for the loads right away, in front of the MFMA cluster they are meant to overlap with
-    auto gload = [&](Stage& t, int k0) {
-        if (k0 + 32 <= K) {
-            if (BMODE == 1) {
-#pragma unroll
-                for (int i = 0; i < BPP; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) t.rbp[i][pl] = *(gch8)(Wp + (obp[i] + k0 + pl * wplane));
-            } else {
-#pragma unroll
-                for (int i = 0; i < BSP; ++i) t.rb[i] = *(gcf4)(W + (ob[i] + k0));
-            }
-            if (AMODE == 1) {
-#pragma unroll
-                for (int i = 0; i < APP; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) t.rap[i][pl] = *(gch8)(Xp + pl * g.xp_plane + (oap[i] + k0));
-            } else {
-#pragma unroll
-                for (int i = 0; i < ASP; ++i) t.ra[i] = *(gcf4)(X + (oa[i] + k0));
-            }
-            return;
-        }
-        const bool pin = k0 + p_k < K, sin = k0 + s_k < K;      // a 16-byte unit is fully inside K or fully outside
-        const int pk = pin ? k0 : -p_k, sk = sin ? k0 : -s_k;
-        const float zm = sin ? 1.f : 0.f;
-        if (BMODE == 1) {
-#pragma unroll
-            for (int i = 0; i < BPP; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
-                    t.rbp[i][pl] = *(gch8)(Wp + (obp[i] + pk + pl * wplane));
-                    if (!pin) t.rbp[i][pl] = (h8){0};
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < BSP; ++i) t.rb[i] = *(gcf4)(W + (ob[i] + sk)) * zm;
-        }
-        if (AMODE == 1) {
-#pragma unroll
-            for (int i = 0; i < APP; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
-                    t.rap[i][pl] = *(gch8)(Xp + pl * g.xp_plane + (oap[i] + pk));
-                    if (!pin) t.rap[i][pl] = (h8){0};
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < ASP; ++i) t.ra[i] = *(gcf4)(X + (oa[i] + sk)) * zm;
-        }
-    };
-    auto put_split = [&](const v4f v, int o) {
-        h4 p[NP];
-        PC::split(v, p);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<h4*>(&smemh[pl * PLANE + o]) = p[pl];
-    };
-    auto put = [&](const Stage& t) {
-        if (AMODE == 1) {
-#pragma unroll
-            for (int i = 0; i < APP; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                    *reinterpret_cast<h8*>(&smemh[pl * PLANE + (p_row + RP * i) * PS + p_k]) = t.rap[i][pl];
-        } else {
-#pragma unroll
-            for (int i = 0; i < ASP; ++i) put_split(t.ra[i], (s_row + RS * i) * PS + s_k);
-        }
-        if (BMODE == 1) {
-#pragma unroll
-            for (int i = 0; i < BPP; ++i)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                    *reinterpret_cast<h8*>(&smemh[pl * PLANE + (BM + p_row + RP * i) * PS + p_k]) = t.rbp[i][pl];
-        } else {
-#pragma unroll
-            for (int i = 0; i < BSP; ++i) put_split(t.rb[i], (BM + s_row + RS * i) * PS + s_k);
-        }
-    };
-
-    v16f acc[2][NJ][NACC];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int a = 0; a < NACC; ++a) acc[i][j][a] = (v16f){0};
-
-    // 16-bit 32x32x16 operand maps: lane (r = l & 31, h = l >> 5) holds A[r][8h .. 8h+7] / B[8h .. 8h+7][r]
-    const int oa0 = (64 * wm + r32) * PS + 8 * half;
-    const int ob0 = (BM + wcol + r32) * PS + 8 * half;
-    auto compute = [&]() {
-        if (!live[0]) return;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h8 b[NJ][NP], a[2][NP];
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) b[j][pl] = *reinterpret_cast<const h8*>(&smemh[pl * PLANE + ob0 + 32 * j * PS + 16 * ks]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i][pl] = *reinterpret_cast<const h8*>(&smemh[pl * PLANE + oa0 + 32 * i * PS + 16 * ks]);
-            }
-            if (ABL & 2) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) { acc[i][0][0][pl] += (float)a[i][pl][0]; acc[i][NJ - 1][0][3 + pl] += (float)b[NJ - 1][pl][1]; }
-                continue;
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (j > 0 && !live[j]) continue;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    v16f& lo = acc[i][j][NACC - 1];
-                    v16f& hi = acc[i][j][0];
-                    if (NP == 3) {
-                        lo = PC::mfma(a[i][NP - 1], b[j][0], lo);
-                        lo = PC::mfma(a[i][0], b[j][NP - 1], lo);
-                        lo = PC::mfma(a[i][1], b[j][1], lo);
-                    }
-                    lo = PC::mfma(a[i][1], b[j][0], lo);
-                    lo = PC::mfma(a[i][0], b[j][1], lo);
-                    hi = PC::mfma(a[i][0], b[j][0], hi);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-        if (32 * u < K) gload(st[u], 32 * u);
-    // ABL & 16 (measurement only): 100 MHz stamps per phase, summed per wave, written to g.tap (tools/gemm_planes_bench.hip)
-    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
-    auto stamp = [&](int k) { if (ABL & 16) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
-    unsigned long long c_begin = 0, t_begin = 0;
-    if (ABL & 16) { tq = t_begin = __builtin_amdgcn_s_memrealtime(); c_begin = __builtin_amdgcn_s_memtime(); }
-    for (int k0 = 0; k0 < K; k0 += 32 * PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int kk = k0 + 32 * u;
-            if (u > 0 && kk >= K) break;
-            __syncthreads();
-            stamp(0);
-            put(st[u]);
-            stamp(1);
-            __syncthreads();
-            stamp(2);
-            if (!(ABL & 1) && kk + 32 * PF < K) gload(st[u], kk + 32 * PF);
-            stamp(3);
-            compute();
-            stamp(4);
-        }
-    }
-    if (ABL & 16) {
-        if (lane == 0) {
-            unsigned long long* d = reinterpret_cast<unsigned long long*>(g.tap) + ((size_t)blockIdx.x * NW + wave) * 8;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) d[k] = tp[k];
-            d[5] = K / 32; d[6] = __builtin_amdgcn_s_memtime() - c_begin; d[7] = __builtin_amdgcn_s_memrealtime() - t_begin + 1;
-        }
-    }
-
-    // epilogue through LDS in units of 8 columns: fp32 rows (two 16-byte stores) and / or the NP planes of the
-    // same 8 values (one 16-byte store per plane)
-    float* const sE = reinterpret_cast<float*>(smemh);
-    typedef const v4f __attribute__((address_space(1)))* gc4;
-    typedef v4f __attribute__((address_space(1)))* g4;
-    constexpr float LO_SCALE = NP == 2 ? 1.f / 2048.f : 1.f;
-    if (ABL & 8) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int a = 0; a < NACC; ++a) t += acc[i][j][a][0] + acc[i][j][a][7];
-        if (t == 123.456f) g.Y[0] = t;
-        return;
-    }
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        __syncthreads();
-        if (wm == hh) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (!live[j]) continue;
-                const int col = wcol + 32 * j + r32;
-                const bool in = n0 + col < N;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        float v = (ACC2 ? acc[i][j][0][reg] + LO_SCALE * acc[i][j][NACC - 1][reg] : acc[i][j][0][reg]) + bias[j];
-                        if (EPI == EPI_LEAKY) v = v >= 0.f ? v : 0.01f * v;
-                        if (!in) v = 0.f;               // pad columns of the output segment stay exactly zero
-                        sE[(32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * half) * ES + col] = v;
-                    }
-            }
-        }
-        __syncthreads();
-        if (g.out_mode == 1) {
-            // fp32 output only: 16-byte units, consecutive lanes store consecutive 16 bytes of a row (whole lines)
-            constexpr int UPR4 = BN / 4;
-#pragma unroll
-            for (int u = 0; u < 64 * UPR4 / TT; ++u) {
-                const int idx = tid + TT * u;
-                const int row = idx / UPR4, c4 = idx % UPR4;
-                const int m = m0 + 64 * hh + row, n = n0 + 4 * c4;
-                if (m < M && n < ((N + 7) & ~7)) {
-                    v4f v = *reinterpret_cast<const v4f*>(&sE[row * ES + 4 * c4]);
-                    if (EPI == EPI_RES || EPI == EPI_MASK) v += *(gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
-                    if (EPI == EPI_MASK) {
-                        if (g.tap) *(g4)((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt) = v;
-                        v *= *(gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
-                    }
-                    if (!(ABL & 4) || v[0] == 123.456f) *(g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy) = v;
-                }
-            }
-            continue;
-        }
-        // plane output (and optionally fp32 beside it): units of 8 columns, one 16-byte store per plane
-        constexpr int UPR = BN / 8;
-#pragma unroll
-        for (int u = 0; u < 64 * UPR / TT; ++u) {
-            const int idx = tid + TT * u;
-            const int row = idx / UPR, c8 = idx % UPR;
-            const int m = m0 + 64 * hh + row, n = n0 + 8 * c8;
-            if (m < M && n < ((N + 7) & ~7)) {
-                v4f v0 = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8]);
-                v4f v1 = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8 + 4]);
-                if (EPI == EPI_RES || EPI == EPI_MASK) {
-                    const gc4 r = (gc4)((gcf)(g.R + job.r_off + n) + (size_t)m * g.ldr);
-                    v0 += r[0]; v1 += r[1];
-                }
-                if (EPI == EPI_MASK) {
-                    if (g.tap) { const g4 t = (g4)((gf)(g.tap + job.m_off + n) + (size_t)m * g.ldt); t[0] = v0; t[1] = v1; }
-                    const gc4 mu = (gc4)((gcf)(g.Mul + job.m_off + n) + (size_t)m * g.ldm);
-                    v0 *= mu[0]; v1 *= mu[1];
-                }
-                if (g.out_mode & 1) {
-                    const g4 y = (g4)((gf)(g.Y + job.y_off + n) + (size_t)m * g.ldy);
-                    y[0] = v0; y[1] = v1;
-                }
-                if (g.out_mode & 2) {
-                    h4 pa[NP], pb[NP];
-                    PC::split(v0, pa);
-                    PC::split(v1, pb);
-                    typedef hT __attribute__((address_space(1)))* ghp;
-                    const ghp yp = (ghp)g.Yp + job.y_off + n + (size_t)m * g.ldy;
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
-                        *(gh8)(yp + pl * g.yp_plane) = __builtin_shufflevector(pa[pl], pb[pl], 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-            }
-        }
-    }
-}
-
-template <int NP, int NT, int AMODE, int BMODE, int ACC2, int PF = 1, int ABL = 0, int NW = 4>
-static void launch_gemm_split(const GemmLaunch& g_in, hipStream_t stream)
-{
-    GemmLaunch g = g_in;
-    const int m_tiles = (g.M + BM - 1) / BM;
-    g.mchunk = gemm_mchunk(m_tiles);
-    const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
-    dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(64 * NW);
-    switch (g.epilogue) {
-    case EPI_LINEAR: hipLaunchKernelGGL((gemm_split_kernel<EPI_LINEAR, NP, NT, AMODE, BMODE, ACC2, PF, ABL, NW>), grid, block, 0, stream, g); break;
-    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_split_kernel<EPI_LEAKY, NP, NT, AMODE, BMODE, ACC2, PF, ABL, NW>), grid, block, 0, stream, g); break;
-    case EPI_RES:    hipLaunchKernelGGL((gemm_split_kernel<EPI_RES, NP, NT, AMODE, BMODE, ACC2, PF, ABL, NW>), grid, block, 0, stream, g); break;
-    default:         hipLaunchKernelGGL((gemm_split_kernel<EPI_MASK, NP, NT, AMODE, BMODE, ACC2, PF, ABL, NW>), grid, block, 0, stream, g); break;
-    }
-}
-
 // =====================================================================================
-// fp16x2 product kernel, pipelined.  Same arithmetic as gemm_split_kernel<NP = 2, AMODE 0, BMODE 1, ACC2> (fp32
-// activations split on the fly, weights as two fp16 planes, hi / lo accumulators), different main loop.  In-kernel
-// stamps of that kernel (tools/gemm_planes_bench.hip, GEMM_TRACE) show a 1.6 us slab of which the MFMAs are 0.37:
-// every wave runs  barrier - split + ds_write - barrier - global-load issue - ds_read + MFMA  in sequence.  Here
+// fp16x2 product kernel, pipelined: fp32 activations split on the fly, weights as two fp16 pieces split once on the
+// host, hi / lo accumulators.  In-kernel stamps of the first, unpipelined version (round 1, profiles/r01_gemm_split_bench.txt)
+// showed a 1.6 us slab of which the MFMAs were 0.37: every wave ran  barrier - split + ds_write - barrier - global-load
+// issue - ds_read + MFMA  in sequence.  Here
 //   * LDS holds TWO stages; a wave splits slab k+1 into stage (k+1)&1 while the MFMAs of slab k (stage k&1) are
 //     in the matrix pipe, and there is ONE barrier per slab;
 //   * the split / ds_write / global-load instructions are placed after the MFMAs they should hide behind and
@@ -703,16 +311,11 @@ static void launch_gemm_split(const GemmLaunch& g_in, hipStream_t stream)
 //     ds_read_b128 fragment reads and the stage at 32 KB (two stages + two workgroups per CU fit in 160 KB).
 // =====================================================================================
 // Epilogue of the fp16x2 kernels: accumulators -> LDS -> 16-byte global stores (whole lines per row), with the fused
-// bias / LeakyReLU / residual / mask variants.  Output as fp32 rows (out_mode & 1) and / or pre-split for the next layer
-// in the weights' slab format (out_mode & 4, LEAKY only: see GemmLaunch::Ys) - the split then happens once per element
-// in the producer instead of once per element and column tile in the consumer.  `omax` returns the largest |value|
-// written as slabs (range guard of the fp16 pieces).
+// bias / LeakyReLU / residual / mask variants.
 template <int EPI, int NT, int TERMS, int SMEM_H>
 __device__ __forceinline__ void h2_epilogue(const GemmLaunch& g, const GemmJob& job, v16f (&acc)[2][NT][2], const float (&bias)[NT],
-                                            const bool (&live)[NT], _Float16* smemh, const int m0, const int n0, const int tid, float& omax)
+                                            const bool (&live)[NT], _Float16* smemh, const int m0, const int n0, const int tid)
 {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr int BN = 64 * NT;
     constexpr int ES2 = BN + 4;                     // staging row stride (floats) of the two-pass epilogue
     // epilogues without extra operands stage the whole 128-row tile at once when LDS has room (one barrier pair, all four
@@ -728,7 +331,6 @@ __device__ __forceinline__ void h2_epilogue(const GemmLaunch& g, const GemmJob& 
     float* const sE = reinterpret_cast<float*>(smemh);
     typedef const v4f __attribute__((address_space(1)))* gc4;
     typedef v4f __attribute__((address_space(1)))* g4;
-    typedef h8 __attribute__((address_space(1)))* gh8_;
     constexpr int UPR4 = BN / 4, NU = RPP * UPR4 / 256;
 #pragma unroll
     for (int hh = 0; hh < HP; ++hh) {
@@ -767,36 +369,7 @@ __device__ __forceinline__ void h2_epilogue(const GemmLaunch& g, const GemmJob& 
             }
         }
         __syncthreads();
-        if ((EPI == EPI_LEAKY) && (g.out_mode & 4)) {
-            // slabs: 8 consecutive columns of a row = 16 bytes of each piece; the 4 units of a 32-deep slab and their
-            // second pieces make one 128-byte line.  Columns up to the next multiple of 32 beyond N are zeros (they
-            // lie in a live 32-column block, staged as zeros above).
-            constexpr int UPR8 = BN / 8;
-            const int nlim = (N + 31) & ~31;
-            const gh8_ Ys = (gh8_)((_Float16 __attribute__((address_space(1)))*)g.Ys + job.ys_off);
-#pragma unroll
-            for (int u = 0; u < RPP * UPR8 / 256; ++u) {
-                const int idx = tid + 256 * u;
-                const int row = idx / UPR8, c8 = idx % UPR8;
-                const int m = m0 + RPP * hh + row, n = n0 + 8 * c8;
-                if (m < M && n < nlim) {
-                    const v4f lo = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8]), hi = *reinterpret_cast<const v4f*>(&sE[row * ES + 8 * c8 + 4]);
-                    omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fabsf(lo[0])), __builtin_fabsf(lo[1]));
-                    omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fabsf(lo[2])), __builtin_fabsf(lo[3]));
-                    omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fabsf(hi[0])), __builtin_fabsf(hi[1]));
-                    omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fabsf(hi[2])), __builtin_fabsf(hi[3]));
-                    h4 p[2], q[2];
-                    Piece<2>::split(lo, p);
-                    Piece<2>::split(hi, q);
-                    const h8 p0 = {p[0][0], p[0][1], p[0][2], p[0][3], q[0][0], q[0][1], q[0][2], q[0][3]};
-                    const h8 p1 = {p[1][0], p[1][1], p[1][2], p[1][3], q[1][0], q[1][1], q[1][2], q[1][3]};
-                    _Float16 __attribute__((address_space(1)))* const d = (_Float16 __attribute__((address_space(1)))*)Ys + (size_t)m * g.ldys + (n >> 5) * 64 + (n & 31);
-                    *(gh8_)d = p0;
-                    *(gh8_)(d + 32) = p1;
-                }
-            }
-        }
-        if (!(EPI == EPI_LEAKY) || (g.out_mode & 1)) {
+        {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int idx = tid + 256 * u;
@@ -1040,9 +613,10 @@ __global__ __launch_bounds__(256, ((NT == 1 || TERMS == 1) ? 3 : 2)) void gemm_h
         for (; k0 < K; k0 += 32) step(std::false_type(), k0);
     }
 
-    float omax = 0.f;
-    h2_epilogue<EPI, NT, TERMS, SMEM_H>(g, job, acc, bias, live, smemh, m0, n0, tid, omax);
-    if (!(__builtin_fmaxf(amax, omax) <= 65504.f) && g.range_flag) *g.range_flag = 1;     // also catches NaN / Inf
+    h2_epilogue<EPI, NT, TERMS, SMEM_H>(g, job, acc, bias, live, smemh, m0, n0, tid);
+    // range guard: a finite operand beyond the fp16 range saturated its first piece.  (NaN operands do not raise it - v_max3
+    // drops them - and need not: they come out as NaN exactly as they do from the fp32 reference.)
+    if (amax > 65504.f && g.range_flag) *g.range_flag = 1;
 }
 
 template <int NT, int ABL = 0, int TERMS = 3>
@@ -1058,166 +632,6 @@ static void launch_gemm_h2(const GemmLaunch& g_in, hipStream_t stream)
     case EPI_LEAKY:  hipLaunchKernelGGL((gemm_h2_kernel<EPI_LEAKY, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
     case EPI_RES:    hipLaunchKernelGGL((gemm_h2_kernel<EPI_RES, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
     default:         hipLaunchKernelGGL((gemm_h2_kernel<EPI_MASK, NT, ABL, TERMS>), grid, block, 0, stream, g); break;
-    }
-}
-
-// =====================================================================================
-// gemm_h2s_kernel: the fp16x2 layer whose INPUT arrives pre-split in slab format (written by the previous layer's
-// epilogue, h2_epilogue out_mode & 4).  Both operands are then fragment-ready in memory, and the whole staging is
-// LDS-DMA: global_load_lds_dwordx4 copies 16 rows x 64 bytes of one piece per instruction straight into the stage
-// (lane-linear LDS image, the 16-byte unit swizzle of the fragment reads applied to the source address) - no staging
-// registers, no split VALU, no ds_write in the main loop.  Same tile geometry, job / tile tables, XCD mapping, LDS
-// layout, MFMA order (bit-identical results) and epilogue as gemm_h2_kernel; two stages, the next slab's copies are
-// issued at the top of a k-step and retired by the vmcnt(0) of its closing barrier.
-// Measured in isolation (tools/gemm_glds_bench.hip, profiles/r01i_gemm_glds_probe.txt): 74 vs 82 us on the PRE0-shaped launch.
-// =====================================================================================
-template <int EPI, int NT>
-__global__ __launch_bounds__(256, (NT == 1 ? 3 : 2)) void gemm_h2s_kernel(GemmLaunch g)
-{
-    typedef _Float16 hT;
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    constexpr int BN = 64 * NT;
-    constexpr int PLANE = (BM + BN) * 32;           // halves per piece and stage: A rows then B rows, 64-byte rows
-    constexpr int STAGE = 2 * PLANE;
-    constexpr int SMEM_H = 2 * STAGE * 2 >= 64 * (BN + 4) * 4 ? 2 * STAGE : 64 * (BN + 4) * 2;
-    __shared__ __attribute__((aligned(16))) hT smemh[SMEM_H];
-
-    const int m_tiles = (g.M + BM - 1) / BM;
-    const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
-    const int mchunk = g.mchunk;
-    const int per_chunk = mchunk * g.n_tiles;
-    const int chunk = (lidx / per_chunk) * 8 + xcd;
-    const int rem = lidx % per_chunk;
-    const int m_tile = chunk * mchunk + rem % mchunk;
-    if (m_tile >= m_tiles) return;
-    const int2 tj = g.tiles[rem / mchunk];
-    const GemmJob job = g.jobs[tj.x];
-    const int n0 = tj.y * BN;
-    const int m0 = m_tile * BM;
-    const int N = job.N, K = job.K, M = g.M;
-    const int nk = (K + 31) >> 5;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, r32 = lane & 31;
-    const int wcol = 32 * NT * wn;
-    float bias[NT];
-    bool live[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int nc = n0 + wcol + 32 * j + r32;
-        bias[j] = ((gcf)job.bias)[nc < N ? nc : N - 1];
-        live[j] = (n0 + wcol + 32 * j) < N;
-    }
-
-    // copy plan of this wave: activation rows 32 wave .. + 31 (two groups of 16) and weight rows BN/4 * wave .. (BG groups)
-    typedef const char __attribute__((address_space(1)))* gcc;
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef const __attribute__((address_space(1))) void* glb_vp;
-    constexpr int BG = BN / 64;
-    const int lrow = lane >> 2, slot = lane & 3;
-    unsigned srcA[2], srcB[BG];                      // byte offsets of this lane's unit in piece 0 of slab 0
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int r = 32 * wave + 16 * s + lrow;
-        int ra = m0 + r; ra = ra < M ? ra : M - 1;
-        srcA[s] = ((unsigned)ra * (unsigned)g.ldxs + (unsigned)job.xs_off + 8u * (unsigned)(slot ^ ((r >> 2) & 3))) * 2u;
-    }
-#pragma unroll
-    for (int s = 0; s < BG; ++s) {
-        const int r = 16 * BG * wave + 16 * s + lrow;
-        int rb = n0 + r; rb = rb < N ? rb : N - 1;
-        srcB[s] = ((unsigned)rb * (unsigned)job.wrow + 8u * (unsigned)(slot ^ ((r >> 2) & 3))) * 2u;
-    }
-    const gcc Ab = (gcc)g.Xs, Bb = (gcc)job.Wp;
-    auto dma = [&](int ks, hT* st) {
-        const unsigned kb = (unsigned)ks * 128u;     // one slab = 128 bytes per row
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                __builtin_amdgcn_global_load_lds((glb_vp)(Ab + (srcA[s] + kb + 64u * pl)), (lds_vp)(st + pl * PLANE + (32 * wave + 16 * s) * 32), 16, 0, 0);
-#pragma unroll
-            for (int s = 0; s < BG; ++s)
-                __builtin_amdgcn_global_load_lds((glb_vp)(Bb + (srcB[s] + kb + 64u * pl)), (lds_vp)(st + pl * PLANE + (BM + 16 * BG * wave + 16 * s) * 32), 16, 0, 0);
-        }
-    };
-
-    v16f acc[2][NT][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) { acc[i][j][0] = (v16f){0}; acc[i][j][1] = (v16f){0}; }
-    const int swz = (r32 >> 2) & 3;
-    const int fa = (64 * wm + r32) * 32, fb = (BM + wcol + r32) * 32;
-    const int fu[2] = {((0 + half) ^ swz) * 8, ((2 + half) ^ swz) * 8};
-
-    // one slab: the first half's fragment reads, then the second half's reads one behind each of the first MFMAs
-    // (one exposed LDS latency per slab), then the remaining MFMAs
-    auto compute = [&](auto fast_tag, const hT* cur) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        h8 b[2][NT][2], a[2][2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) b[ks][j][pl] = *reinterpret_cast<const h8*>(&cur[pl * PLANE + fb + 32 * j * 32 + fu[ks]]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[ks][i][pl] = *reinterpret_cast<const h8*>(&cur[pl * PLANE + fa + 32 * i * 32 + fu[ks]]);
-            }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (!FAST && !live[j]) continue;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][1], b[ks][j][0], acc[i][j][1], 0, 0, 0);
-                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][0], b[ks][j][1], acc[i][j][1], 0, 0, 0);
-                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][i][0], b[ks][j][0], acc[i][j][0], 0, 0, 0);
-                }
-            }
-        if (FAST) {
-            constexpr int NR = 2 * (NT + 2);         // fragment reads per half
-            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 12 * NT - NR, 0);
-        }
-    };
-    const bool fast = live[NT - 1];
-    if (nk > 0) dma(0, smemh);
-    __syncthreads();                                // (with the vmcnt(0) that retires the copies)
-    for (int ks = 0; ks < nk; ++ks) {
-        if (ks + 1 < nk) dma(ks + 1, smemh + ((ks + 1) & 1) * STAGE);
-        if (fast) compute(std::true_type(), smemh + (ks & 1) * STAGE);
-        else if (live[0]) compute(std::false_type(), smemh + (ks & 1) * STAGE);
-        __syncthreads();
-    }
-
-    float omax = 0.f;
-    h2_epilogue<EPI, NT, 3, SMEM_H>(g, job, acc, bias, live, smemh, m0, n0, tid, omax);
-    if (!(omax <= 65504.f) && g.range_flag) *g.range_flag = 1;
-}
-
-template <int NT>
-static void launch_gemm_h2s(const GemmLaunch& g_in, hipStream_t stream)
-{
-    GemmLaunch g = g_in;
-    const int m_tiles = (g.M + BM - 1) / BM;
-    g.mchunk = gemm_mchunk(m_tiles);
-    const int chunks = (m_tiles + g.mchunk - 1) / g.mchunk;
-    dim3 grid(8 * ((chunks + 7) / 8) * g.mchunk * g.n_tiles), block(256);
-    switch (g.epilogue) {
-    case EPI_LINEAR: hipLaunchKernelGGL((gemm_h2s_kernel<EPI_LINEAR, NT>), grid, block, 0, stream, g); break;
-    case EPI_LEAKY:  hipLaunchKernelGGL((gemm_h2s_kernel<EPI_LEAKY, NT>), grid, block, 0, stream, g); break;
-    case EPI_RES:    hipLaunchKernelGGL((gemm_h2s_kernel<EPI_RES, NT>), grid, block, 0, stream, g); break;
-    default:         hipLaunchKernelGGL((gemm_h2s_kernel<EPI_MASK, NT>), grid, block, 0, stream, g); break;
     }
 }
 
@@ -1238,15 +652,18 @@ static void launch_gemm_nt(const GemmLaunch& g_in, hipStream_t stream)
     }
 }
 
+static thread_local bool tl_force_f32 = false;
+void set_force_f32(bool on) { tl_force_f32 = on; }
+bool force_f32() { return tl_force_f32; }
+
 int gemm_mode()
 {
     static const int mode = [] {
         const char* e = getenv("BSRNN_GEMM");
         if (!e || !*e || !strcmp(e, "fp16x2")) return (int)GEMM_FP16X2;
         if (!strcmp(e, "f32")) return (int)GEMM_F32;
-        if (!strcmp(e, "bf16x3")) return (int)GEMM_BF16X3;
         if (!strcmp(e, "fp16")) return (int)GEMM_FP16;
-        fprintf(stderr, "bsrnn: unknown BSRNN_GEMM='%s' (f32 | fp16x2 | bf16x3 | fp16), using fp16x2\n", e);
+        fprintf(stderr, "bsrnn: unknown BSRNN_GEMM='%s' (f32 | fp16x2 | fp16), using fp16x2\n", e);
         return (int)GEMM_FP16X2;
     }();
     return mode;
@@ -1255,23 +672,14 @@ int gemm_mode()
 void launch_gemm(const GemmLaunch& g, hipStream_t stream)
 {
     if (g.M <= 0 || g.n_tiles <= 0) return;
-    switch (gemm_mode()) {
+    switch (force_f32() ? (int)GEMM_F32 : gemm_mode()) {
     case GEMM_FP16X2:
-        if (g.Xs) {                                  // input pre-split by the producing layer: LDS-DMA kernel
-            if (g.tile_n == 128) launch_gemm_h2s<2>(g, stream);
-            else launch_gemm_h2s<1>(g, stream);
-            return;
-        }
         if (g.tile_n == 128) launch_gemm_h2<2>(g, stream);
         else launch_gemm_h2<1>(g, stream);
         return;
     case GEMM_FP16:
         if (g.tile_n == 128) launch_gemm_h2<2, 0, 1>(g, stream);
         else launch_gemm_h2<1, 0, 1>(g, stream);
-        return;
-    case GEMM_BF16X3:
-        if (g.tile_n == 128) launch_gemm_split<3, 2, 0, 1, 0, 2>(g, stream);
-        else launch_gemm_split<3, 1, 0, 1, 0, 1>(g, stream);
         return;
     default: break;
     }

@@ -16,15 +16,14 @@ constexpr int F2 = 2050;      // interleaved re/im columns
 // per-band MLP chains over all M = C*T frame rows.
 struct GemmJob {
     const float* W;      // [N][K] row-major (torch Linear layout), device, K padded to a multiple of 8 floats
-    const void* Wp;      // the same matrix split into three bf16 planes [3][N][K] (gemm.hip, "planes" kernel)
+    const void* Wp;      // the same matrix as two fp16 pieces, slab-interleaved [N][K32 / 32][2][32] (split_host.h)
     const float* bias;   // [N]
     int N, K;            // K may be 0: y = bias (TrainableConstantModule, bsrnn.py:12-24)
     int x_off;           // column offset of the job's input inside an X row
     int y_off;           // column offset of the output inside a Y row
     int r_off;           // column offset inside the residual row (EPI_RES, EPI_MASK)
     int m_off;           // column offset inside the multiplier / mask-tap row (EPI_MASK)
-    int wrow;            // fp16x2 slab format: 16-bit elements between consecutive weight rows of Wp
-    int xs_off, ys_off;  // slab-format activations (GemmLaunch::Xs / Ys): 16-bit element offset of the job's first slab in a row
+    int wrow;            // 16-bit elements between consecutive weight rows of Wp
 };
 
 enum GemmEpilogue {
@@ -47,25 +46,62 @@ struct GemmLaunch {
     float* tap; int ldt;     // optional mask tap (EPI_MASK), may be null
     int M;
     int epilogue;
-    // split-precision ("planes") kernel only: activations as three bf16 planes, plane p of an [M][ld] matrix
-    // starts p * plane elements after the first; columns use the same offsets and ld as X / Y
-    const void* Xp; size_t xp_plane;   // input planes; null: X is fp32 and is split on the fly
-    void* Yp; size_t yp_plane;         // output planes (written when out_mode & 2)
-    int out_mode;                      // bit 0: write fp32 Y, bit 1: write planes Yp, bit 2: write slabs Ys
-    // fp16x2 mode, activations pre-split by the producing layer's epilogue in the weights' slab format
-    // [row][K32 / 32][2 pieces][32] fp16 (both pieces of a 32-deep slab of a row share one 128-byte line; columns from
-    // N up to the next multiple of 32 are written as zeros): the consumer copies them global -> LDS by LDS-DMA.
-    const void* Xs; int ldxs;          // input slabs (null: X is fp32 and is split on the fly); ld in 16-bit elements
-    void* Ys; int ldys;                // output slabs (written when out_mode & 4)
     int* range_flag;                   // fp16x2: set to 1 when an operand exceeded the fp16 range (may be null)
 };
 void launch_gemm(const GemmLaunch& g, hipStream_t stream);
-// How the Linear layers are evaluated (environment BSRNN_GEMM = f32 | fp16x2 | bf16x3 | fp16, read once per process).
+// How the Linear layers are evaluated (environment BSRNN_GEMM = f32 | fp16x2 | fp16, read once per process).
 // fp16 = plain 16-bit operands, one MFMA term, fp32 accumulate (the reduced-precision configuration, not the default).
-// f32: no 16-bit weights; fp16x2 / fp16: slab-interleaved fp16 pieces; bf16x3: three bf16 planes.
-enum GemmMode { GEMM_F32 = 0, GEMM_FP16 = 1, GEMM_FP16X2 = 2, GEMM_BF16X3 = 3 };
+// The fp32 weights are always resident beside the fp16 pieces: a call whose operands left the fp16x2 range is re-run on
+// the exact-fp32 kernels (set_force_f32, per host thread) by the synchronous entry points of api.hip.
+enum GemmMode { GEMM_F32 = 0, GEMM_FP16 = 1, GEMM_FP16X2 = 2 };
 int gemm_mode();
+void set_force_f32(bool on);
+bool force_f32();
 constexpr int GEMM_BM = 128;
+
+// ------------------------------------------------------------------ fused per-band MLP chains (mlp_chain.hip)
+// One workgroup = one band x one block of frame rows, all five Linear layers of BandSplit (bsrnn.py:404-415) or of
+// MaskEstimation (bsrnn.py:420-443); intermediates stay in LDS as fp16x2 pieces.
+constexpr int CHAIN_LAYERS = 5;
+constexpr int CHAIN_CT = 3;                   // feature tiles (32 wide) per wave and layer, at most
+constexpr int CHAIN_LDS_EX = 96 * 1024;       // activation images of the workgroup's row tiles
+constexpr int CHAIN_LDS_BIAS = 16 * 1024;     // the chain's biases
+enum { CHAIN_SPLIT = 0, CHAIN_MASK = 1 };
+struct ChainLayer {
+    int K16;             // k-steps of 16 (input width rounded up)
+    int NTL;             // feature tiles of 32 (output width rounded up); weights and biases beyond N are zero
+    int bias_off;        // first bias of the layer inside the chain's bias block (floats)
+    int leaky;           // LeakyReLU(0.01) after the layer
+    unsigned w_off;      // byte offset of the layer's fragment streams inside ChainDesc::wstream
+};
+struct ChainDesc {
+    ChainLayer L[CHAIN_LAYERS];
+    const void* wstream; // per layer, per wave wn: for ks, for tile t = wn + NW c, for piece: 64 lanes x 8 fp16 (split_host.h)
+    const float* bias;   // the five bias vectors, each padded with zeros to NTL * 32 (constant band: the constant itself)
+    int nbias;
+    int NW, RT;          // waves per row tile, row tiles (of 32 rows) per workgroup; NW * RT = 8
+    int plane_units;     // 512-byte units of one piece of one row tile's activation image: max(2 K16, 4 NTL) over the layers
+    int in_off;          // first column of the band inside an input row (SPLIT: spectrum row, MASK: b * 64 of a Z row)
+    int K0;              // valid input columns, a multiple of 8 (beyond: zeros)
+    int p_off;           // first column of the band in the band-padded rows (P, spectrum, output)
+    int a8;              // band width in columns rounded up to 8: what is written to P / Y (pad columns exactly zero)
+    int z_off;           // first column of the band inside a Z row
+    int constant;        // zero-width band (TrainableConstantModule, bsrnn.py:12-24): Z[:, z_off .. +64) = bias[0 .. 64)
+};
+struct ChainLaunch {
+    const ChainDesc* desc;   // device array, grouped by class: RT = 1, then 2, then 4, then the constant bands (256 rows per
+    int n_cls[4];            //   workgroup); heaviest band first inside a class.  Blocks = sum n_cls[i] * ceil(M / rows_i).
+    int M;
+    const float* Xin; int ldx;       // SPLIT: spectrum rows; MASK: Z rows
+    float* P; int ldp;               // SPLIT: written (bandFCs_pre output = the mask's residual); MASK: read
+    float* Z; int ldz;               // SPLIT: written
+    const float* Xmul; int ldm;      // MASK: the spectrum the mask multiplies
+    float* Y; int ldy;               // MASK: x * mask
+    float* tap; int ldt;             // MASK: the mask itself (optional)
+    int* range_flag;
+};
+int chain_blocks(const ChainLaunch& g);
+void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 
 // ------------------------------------------------------------------ dual-path LSTM kernels
 // Band-axis BLSTM layer (both directions in one launch): N sequences of length L.

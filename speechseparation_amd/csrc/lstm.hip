@@ -380,7 +380,7 @@ void launch_band_lstm(const float* xin, float* hout, const float* wpk, const voi
 {
     if (N <= 0 || L <= 0) return;
     dim3 grid((N + 15) / 16, 2), block(256);
-    if (lstm_mode() == LSTM_FP16X2) {
+    if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
         if (IN == 64)
             hipLaunchKernelGGL(band_lstm_h2_kernel<64>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, range_flag, (unsigned long long*)nullptr);
         else
@@ -789,7 +789,7 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const voi
     const int N = R * K;
     if (N <= 0 || T <= 0) return;
     dim3 grid((N + 3) / 4), block(512);
-    if (lstm_mode() == LSTM_FP16X2) {
+    if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
         hipLaunchKernelGGL(time_lstm_h2_kernel<false>, grid, block, 0, stream, zin, hout, (const uint4*)wpk16, bias, state_in, state_out, R, T, K,
                            range_flag, (unsigned long long*)nullptr);
         return;

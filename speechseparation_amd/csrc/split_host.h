@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 namespace bsrnn {
 
@@ -74,6 +75,27 @@ inline void pack_h2_slabs_host(const float* w, int N, int K, int ldw, int K32, i
             o[0] = pc[0];
             o[32] = pc[1];
         }
+}
+
+// Fragment streams of one Linear layer for the fused chain kernel (mlp_chain.hip): the weights are the MFMA's A operand
+// (v_mfma_f32_32x32x16_f16: lane (r = l & 31, h = l >> 5) holds W[32 t + r][16 ks + 8 h + j], j < 8) and every wave of a
+// row tile walks its own linear stream: for wave wn of NW, for k-step ks, for its tiles t = wn, wn + NW, ..., for piece
+// (npl = 2: fp16x2, 1: plain fp16): 64 lanes x 8 halves = 1 KB.  Rows >= N and columns >= K are zeros.  Appends to `out`.
+inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out)
+{
+    const int K16 = (K + 15) / 16, NTL = (N + 31) / 32;
+    for (int wn = 0; wn < NW; ++wn)
+        for (int ks = 0; ks < K16; ++ks)
+            for (int t = wn; t < NTL; t += NW)
+                for (int pc = 0; pc < npl; ++pc)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = 32 * t + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
+                            const float v = (n < N && k < K) ? w[(size_t)n * ldw + k] : 0.f;
+                            uint16_t p[2];
+                            split_planes_host(&v, 1, 2, p);
+                            out.push_back(p[pc]);
+                        }
 }
 
 inline float join_planes_host(const uint16_t* planes, size_t n, size_t i, int np)

@@ -14,6 +14,8 @@ if kind.startswith("load"):          # "load" = separate(); "load:stft" / "load:
     xl = m.stft(w)
     zl = torch.zeros((65, 17, 12, 64), device="cuda")
     body = {"separate": lambda: m.separate(w), "stft": lambda: m.stft(w), "forward": lambda: m(xl), "dual": lambda: m.dual_path(zl)}[what]
+    body(); torch.cuda.synchronize()
+    print("load ready", flush=True)      # the test waits for this line: from here on the GPU is busy
     for _ in range(reps):
         body()
     torch.cuda.synchronize(); print("load done"); sys.exit(0)

@@ -137,16 +137,15 @@ def test_reference_checkpoint_interchange(tmp_path, built):
     assert subprocess.run([sys.executable, tool, bad, flat], capture_output=True).returncode != 0
 
 
-@pytest.mark.gpu
 def test_io_signature_matches_the_exported_onnx_naming(built):
     """bsrnn_io_info: names and shapes of the reference's ONNX export (infer-streaming.py:74; speech-ladspa-onnx.cpp:82-111
-    sizes its state from the input called "state.0").  (A context needs a HIP device, hence the gpu mark.)"""
+    sizes its state from the input called "state.0").  Host-only context: no GPU needed."""
     from speechseparation_amd import _native
     lib = _native.lib
     v = spec.generate_bandsplits()[0]
     ctx = ctypes.c_void_p()
     widths = (ctypes.c_int32 * len(v))(*v)
-    assert lib.bsrnn_create(0, widths, len(v), ctypes.byref(ctx)) == 0, lib.bsrnn_last_error().decode()
+    assert lib.bsrnn_create(-1, widths, len(v), ctypes.byref(ctx)) == 0, lib.bsrnn_last_error().decode()
     try:
         assert lib.bsrnn_io_count() == 4
         got = []
@@ -158,5 +157,101 @@ def test_io_signature_matches_the_exported_onnx_naming(built):
         assert got == [("x.0", True, (2, 2050)), ("state.0", True, (4, 2, 24, 64)),
                        ("y.0", False, (2, 2050)), ("new_state.0", False, (4, 2, 24, 64))]
         assert lib.bsrnn_io_info(ctx, 4, 2, None, None, (ctypes.c_int64 * 4)(), ctypes.byref(ctypes.c_int32())) != 0
+    finally:
+        lib.bsrnn_destroy(ctx)
+
+
+# ----------------------------------------------------------------------------- weight-file loader (host-only context)
+def _host_ctx():
+    """A host-only context (device -1): inventory + parameter staging + file validation, no GPU needed."""
+    from speechseparation_amd import _native
+    v = spec.generate_bandsplits()[0]
+    widths = (ctypes.c_int32 * len(v))(*v)
+    ctx = ctypes.c_void_p()
+    _native.check(_native.lib.bsrnn_create(-1, widths, len(v), ctypes.byref(ctx)))
+    return _native, ctx
+
+
+def test_host_only_context_validates_but_does_not_compute(built, tmp_path):
+    _native, ctx = _host_ctx()
+    lib = _native.lib
+    try:
+        assert lib.bsrnn_device(ctx) == -1 and lib.bsrnn_param_count(ctx) == 288
+        sd = weights.synth_state_dict(seed=0)
+        path = str(tmp_path / "w.bin")
+        weights.save_flat(path, sd)
+        assert lib.bsrnn_load_weights_file(ctx, path.encode()) == 0          # every key, rank and shape matches the inventory
+        k = "bandFCs.9.0.weight"
+        back = np.empty(sd[k].shape, np.float32)
+        assert lib.bsrnn_get_param(ctx, k.encode(), back.ctypes.data_as(ctypes.c_void_p), back.size) == 0
+        assert np.array_equal(back, sd[k])
+        x = np.zeros(4, np.float32)
+        rc = lib.bsrnn_separate(ctx, x.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p), 1, 4096, None)
+        assert rc == 2 and b"host-only" in lib.bsrnn_last_error()            # BSRNN_ESTATE: no CPU compute path exists
+    finally:
+        lib.bsrnn_destroy(ctx)
+
+
+def test_weight_file_loader_rejects_malformed_files(built, tmp_path):
+    """The loader trusts nothing in the file: truncation, huge or overflowing dims, a transposed matrix of the right element
+    count, a wrong rank, an unknown key and a wrong band table are all refused with an error code - no exception crosses
+    the C ABI and no allocation is sized from the file."""
+    import struct
+    _native, ctx = _host_ctx()
+    lib = _native.lib
+    sd = weights.synth_state_dict(seed=0)
+    good = str(tmp_path / "good.bin")
+    weights.save_flat(good, sd)
+    blob = open(good, "rb").read()
+    v = spec.generate_bandsplits()[0]
+    head = 8 + 4 + 4 * len(v) + 4                                   # magic, band count, widths, tensor count
+    first_key = next(iter(sd))                                      # bandFCs_pre.0.0.weight [2, 2]
+    kl = len(first_key.encode())
+    dims_at = head + 4 + kl + 4                                     # first tensor's dims
+    EIO, ENOKEY = 4, 5
+
+    def load(data, name):
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        rc = lib.bsrnn_load_weights_file(ctx, p.encode())
+        return rc, lib.bsrnn_last_error().decode()
+
+    try:
+        assert load(blob, "ok.bin")[0] == 0
+        for cut in (7, head - 2, dims_at + 3, len(blob) // 2, len(blob) - 1):
+            rc, msg = load(blob[:cut], "cut%d.bin" % cut)
+            assert rc == EIO, (cut, rc, msg)
+        # dims whose product overflows uint64 / would ask for exabytes: refused before anything is allocated
+        huge = bytearray(blob)
+        huge[dims_at:dims_at + 16] = struct.pack("<2Q", 1 << 40, 1 << 40)
+        rc, msg = load(bytes(huge), "huge.bin")
+        assert rc == EIO and "shape" in msg
+        # same element count, transposed shape: must not be accepted silently
+        k = "bandFCs.0.0.weight"                                     # [64, 2]
+        tr = dict(sd)
+        tr[k] = np.ascontiguousarray(sd[k].T)
+        p = str(tmp_path / "tr.bin")
+        weights.save_flat(p, tr)
+        rc = lib.bsrnn_load_weights_file(ctx, p.encode())
+        assert rc == EIO and "shape of 'bandFCs.0.0.weight'" in lib.bsrnn_last_error().decode()
+        # wrong rank
+        fl = dict(sd)
+        fl[k] = sd[k].reshape(-1)
+        weights.save_flat(p, fl)
+        assert lib.bsrnn_load_weights_file(ctx, p.encode()) == EIO and "rank" in lib.bsrnn_last_error().decode()
+        # unknown key
+        uk = dict(sd)
+        uk["not.a.key"] = np.zeros(3, np.float32)
+        weights.save_flat(p, uk)
+        rc = lib.bsrnn_load_weights_file(ctx, p.encode())
+        assert rc in (EIO, ENOKEY)
+        # absurd key length
+        bad = bytearray(blob)
+        bad[head:head + 4] = struct.pack("<I", 1 << 30)
+        assert load(bytes(bad), "kl.bin")[0] == EIO
+        # another band table
+        weights.save_flat(p, sd, v=[1025, 0])
+        assert lib.bsrnn_load_weights_file(ctx, p.encode()) == EIO
+        assert lib.bsrnn_load_weights_file(ctx, str(tmp_path / "missing.bin").encode()) == EIO
     finally:
         lib.bsrnn_destroy(ctx)

@@ -31,9 +31,13 @@ def test_results_do_not_depend_on_a_busy_gpu(sd_default):
     quiet["istft"] = m.istft(torch.from_numpy(quiet["stft"]).cuda()).cpu().numpy()
     env = dict(os.environ, PYTHONPATH=REPO)
     load = subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "coresident_check.py"), "load", "150000"], env=env, cwd=REPO,
-                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     try:
-        time.sleep(12)                                   # import + model build of the load process
+        # wait for the load process to say that it has built its model and started its loop (import + build take a
+        # variable time on a fresh box; a fixed sleep would let the check run beside an idle GPU and pass vacuously)
+        t0 = time.time()
+        line = load.stdout.readline()
+        assert line.strip() == "load ready", "background load did not start: %r after %.0f s" % (line, time.time() - t0)
         assert load.poll() is None, "the background load ended before the check started"
         xs = torch.from_numpy(quiet["stft"]).cuda()
         for _ in range(10):

@@ -157,3 +157,87 @@ def test_large_batches_equal_their_row_blocks(sd_default):
     rows = [0, 64, 65, 129]
     ref = onp.separate(sd_default, wave[rows])
     assert maxabs(whole[rows], ref) < TOL
+
+
+def test_stream_survives_regrow_and_recommit(sd_default, sd_hot):
+    """A streaming step replays a captured hipGraph that holds the context's workspace and weight-arena pointers.  A larger
+    call on the same model (workspace regrown and freed) and a load_state_dict (arena rebuilt) between two steps must
+    lead to a re-capture, not to a replay into freed memory: every step equals the oracle's."""
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    from speechseparation_amd.bsrnn import StreamingSeparator
+    m = make_model(sd_default)
+    st = StreamingSeparator(m, channels=2)
+    so = onp.StreamingOracle(sd_default, C=2)
+    chunks = weights.synth_waveform(2, 6 * 1024, seed=77)
+    def step(i, oracle):
+        c = chunks[:, i * 1024:(i + 1) * 1024]
+        out = st.step(torch.from_numpy(c.copy()).cuda()).cpu().numpy()
+        e = maxabs(out, oracle.step(c))
+        assert e < TOL, (i, e)
+    step(0, so)
+    step(1, so)
+    big = weights.synth_waveform(40, 20 * 1024 + 5, seed=78)          # 840 frame rows: far beyond the stream's 2-row workspace
+    ref_big = onp.separate(sd_default, big[:2])
+    assert maxabs(m.separate(torch.from_numpy(big).cuda()).cpu().numpy()[:2], ref_big) < TOL
+    step(2, so)                                                         # workspace was regrown: graph re-captured
+    # new weights into the same model: the stream keeps its DSP state and LSTM state, the oracle gets the same switch
+    m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd_hot.items()})
+    so.sd = sd_hot
+    step(3, so)
+    bigger = weights.synth_waveform(48, 20 * 1024 + 5, seed=79)
+    m.separate(torch.from_numpy(bigger).cuda())
+    step(4, so)
+    step(5, so)
+
+
+def test_context_outlives_destroy_while_a_stream_is_alive(sd_default):
+    """bsrnn_destroy with a live stream retires the context instead of freeing what the stream points at."""
+    import ctypes
+    from speechseparation_amd import _native
+    lib = _native.lib
+    m = make_model(sd_default)
+    ctx = m._context(torch.device("cuda", 0))
+    h = ctypes.c_void_p()
+    _native.check(lib.bsrnn_stream_create(ctx, 2, ctypes.byref(h)))
+    lib.bsrnn_destroy(ctx)                                # deferred: the stream still holds the context
+    m._ctx = None                                         # the model must not destroy it a second time
+    x = torch.zeros((2, 1024), device="cuda")
+    rc = lib.bsrnn_stream_step(h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_float(1.0), None)
+    assert rc == 2 and b"destroyed" in lib.bsrnn_last_error()        # BSRNN_ESTATE, not a crash
+    lib.bsrnn_stream_destroy(h)                           # the last stream takes the context with it
+    torch.cuda.synchronize()
+
+
+def test_synchronous_entry_points_rerun_out_of_range_calls_in_fp32(sd_default):
+    """|x| ~ 1e7 saturates the fp16x2 operand pieces.  The synchronous entry points (host-buffer streaming step, evaluate)
+    must notice before they return and hand back the exact-fp32 result of the same call (rc 0), not saturated numbers one
+    call early and an error one call late."""
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import _native, weights
+    from speechseparation_amd.bsrnn import StreamingSeparator
+    if _native.compute_mode()["gemm"] != "fp16x2":
+        pytest.skip("range guard belongs to the fp16x2 mode")
+    m = make_model(sd_default)
+    st = StreamingSeparator(m, channels=2)
+    so = onp.StreamingOracle(sd_default, C=2, dtype=np.float64)
+    chunks = weights.synth_waveform(2, 5 * 1024, seed=91).astype(np.float64)
+    scale = [1.0, 1.0, 3e5, 1.0, 1.0]                     # chunk 2 drives the spectrum to |x| ~ 1e7
+    for i in range(5):
+        c = (chunks[:, i * 1024:(i + 1) * 1024] * scale[i]).astype(np.float32)
+        out = st.step(torch.from_numpy(c.copy())).numpy()          # host tensors -> bsrnn_stream_step_host
+        ref = so.step(c)
+        rel = maxabs(out, ref) / max(np.abs(ref).max(), 1e-30)
+        print("step %d: |ref|max %.3g relative error %.2e" % (i, np.abs(ref).max(), rel))
+        assert rel < 2e-6, (i, rel)
+    # evaluate(): same guarantee
+    mix = weights.synth_waveform(2, 6 * 1024, seed=92)
+    big = (mix * 3e5).astype(np.float32)
+    r = m.evaluate(torch.from_numpy(big).cuda(), torch.from_numpy(big * 0.5).cuda(), return_estimate=True)
+    ref = onp.separate(sd_default, big, dtype=np.float64)
+    rel = maxabs(r["x_time"].cpu().numpy(), ref) / np.abs(ref).max()
+    print("evaluate: relative error of the estimate %.2e" % rel)
+    assert rel < 2e-6
+    # and nothing is left pending: the next call on the context succeeds
+    m.separate(torch.from_numpy(mix).cuda())
+    torch.cuda.synchronize()

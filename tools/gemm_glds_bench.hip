@@ -346,7 +346,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(dT, tiles128.data(), tiles128.size() * sizeof(int2), hipMemcpyHostToDevice));
     GemmLaunch g = {};
     g.jobs = dJ; g.tiles = dT; g.n_tiles = (int)tiles128.size(); g.tile_n = 128;
-    g.X = dX; g.ldx = LD; g.Y = dY; g.ldy = LD; g.M = M; g.epilogue = EPI_LEAKY; g.out_mode = 1;
+    g.X = dX; g.ldx = LD; g.Y = dY; g.ldy = LD; g.M = M; g.epilogue = EPI_LEAKY;
     GemmLaunch g2 = g; g2.Y = dY2;
     double flop = 0;
     for (auto& j : jobs) flop += 2.0 * j.N * j.K * M;
