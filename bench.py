@@ -59,15 +59,24 @@ def exact_macs(v):
             "time_lstm": time_, "time_fc": 2 * K * H * H}
 
 
-def gemm_activation_bytes(v):
-    """Algorithmic activation bytes per row-frame of the ten grouped-GEMM launches (fp32: every layer reads its
-    input once and writes its output once; the last one also reads the residual and the spectrum it multiplies).
-    The per-band layers are only 2*K flop per activation byte deep, so this is a second floor beside the matrix pipe."""
+def mlp_flow(gemm):
+    """'fused' (mlp_chain.hip: one launch per chain, intermediates in LDS) unless the per-layer flow was asked for
+    (BSRNN_MLP=layers) or the exact-fp32 mode runs (per-layer fp32 MFMA kernels)."""
+    return "layers" if (gemm == "f32" or os.environ.get("BSRNN_MLP") == "layers") else "fused"
+
+
+def gemm_activation_bytes(v, flow="layers"):
+    """Algorithmic activation bytes per row-frame of the MLP launches (fp32: every launch reads its input once and writes
+    its output once).  Per-layer flow: ten launches, the last one also reads the residual and the spectrum it multiplies.
+    Fused flow: BandSplit reads the spectrum and writes the residual P and Z; MaskEstimation reads Z, P and the spectrum
+    and writes the masked spectrum (8200 + 8200 + 3072, and 3072 + 8200 + 8200 + 8200 B at K = 12)."""
     H = 64
     a = [2 * w for w in v if w]
     m = [max(x, H) for x in a]
     p = [max(x, 2 * H) for x in a]
     n = len(a)
+    if flow == "fused":
+        return 4 * ((sum(a) + sum(a) + n * H) + (n * H + 3 * sum(a)))
     cols = (sum(a) + sum(a)) + (sum(a) + sum(a)) + (sum(a) + sum(m)) + (sum(m) + n * H) + (n * H + n * H)        # PRE0 PRE2 FC0 FC2 FC4
     cols += (n * H + n * 2 * H) + (n * 2 * H + sum(p)) + (sum(p) + sum(a)) + (sum(a) + sum(a)) + (sum(a) + 3 * sum(a))   # BACK0 BACK2 BACK4 POST0 POST2
     return 4 * cols
@@ -96,6 +105,10 @@ def host_cores():
 # The ten grouped-GEMM launches of the two bracketed stages, by kernel instance (template arguments as rocprofv3
 # prints them) -> launches per step.  gemm_h2_kernel<epilogue, tile (1 = 128x64, 2 = 128x128), ablation>;
 # gemm_split_kernel<epilogue, pieces, tile, ...>.
+FUSED_LAUNCH_MIX = {        # mlp_chain_kernel<chain (0 BandSplit, 1 MaskEstimation), MFMA terms>
+    "fp16x2": (("mlp_chain_kernel<0, 3>", 1), ("mlp_chain_kernel<1, 3>", 1)),
+    "fp16": (("mlp_chain_kernel<0, 1>", 1), ("mlp_chain_kernel<1, 1>", 1)),
+}
 GEMM_LAUNCH_MIX = {
     "f32": (("gemm_f32_kernel<1,", 8), ("gemm_f32_kernel<0,", 1), ("gemm_f32_kernel<3,", 1)),
     "fp16x2": (("gemm_h2_kernel<1, 2,", 6), ("gemm_h2_kernel<1, 1,", 2), ("gemm_h2_kernel<0, 1,", 1), ("gemm_h2_kernel<3, 2,", 1)),
@@ -111,7 +124,7 @@ GEMM_ROOF = {
 }
 
 
-def profiled_traffic(gemm):
+def profiled_traffic(gemm, flow="layers"):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/rNN_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE and
     WRITE_SIZE passes with the gfx950 x2 fetch correction).  The bracketed stages launch the LEAKY
@@ -122,12 +135,13 @@ def profiled_traffic(gemm):
         return None, None
     d = json.load(open(files[-1]))
     tot = 0.0
-    for key, n in GEMM_LAUNCH_MIX[gemm]:
+    mix = FUSED_LAUNCH_MIX[gemm] if flow == "fused" else GEMM_LAUNCH_MIX[gemm]
+    for key, n in mix:
         hit = [v for k, v in d.items() if k.startswith(key)]
         if not hit:
             return None, None
         tot += n * (hit[0]["fetched_bytes"] + hit[0]["written_bytes"])
-    return tot / 10.0, os.path.basename(files[-1])
+    return tot / sum(n for _, n in mix), os.path.basename(files[-1])
 
 
 def build_model(device):
@@ -341,22 +355,27 @@ def main():
         # what the timed-region events bracket (5 launches per bracket)
         dom_ms_step = sum(dom_stages[k][0] for k in DOMINANT) / args.steps
         dom_flop_step = 2 * sum(macs[k] for k in DOMINANT) * rf
-        n_launch = 10
         from speechseparation_amd import _native
         cmode = _native.compute_mode()
+        flow = mlp_flow(cmode["gemm"])
+        n_launch = 2 if flow == "fused" else 10
         kname, peak, basis = GEMM_ROOF[cmode["gemm"]]
-        traffic, traffic_src = profiled_traffic(cmode["gemm"])
+        if flow == "fused":
+            kname = "mlp_chain_kernel"
+        traffic, traffic_src = profiled_traffic(cmode["gemm"], flow)
         achieved = dom_flop_step / (dom_ms_step * 1e-3) / 1e12
-        roofline = {"kernel": "%s (grouped per-band Linear layers: bandsplit_mlp + mask_mlp, %d launches/step)" % (kname, n_launch),
+        act_bytes = gemm_activation_bytes(spec.generate_bandsplits()[0], flow)
+        roofline = {"kernel": "%s (the per-band MLP chains BandSplit + MaskEstimation, %s: %d launches/step)" % (
+                        kname, "fused, intermediates in LDS" if flow == "fused" else "one grouped launch per layer", n_launch),
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms_step / n_launch, 4), "launches_per_step": n_launch,
                     "flop_per_launch_avg": dom_flop_step / n_launch, "peak_basis": basis,
                     "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "hbm_view": {"algorithmic_bytes_per_launch_avg": gemm_activation_bytes(spec.generate_bandsplits()[0]) * rf / n_launch,
-                                 "achieved_GBs": round(gemm_activation_bytes(spec.generate_bandsplits()[0]) * rf / (dom_ms_step * 1e-3) / 1e9, 1),
-                                 "frac_of_hbm_peak": round(gemm_activation_bytes(spec.generate_bandsplits()[0]) * rf / (dom_ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                 "note": "the same launches against HBM: activations in + out per layer (2*K flop per byte only), weights excluded"},
+                    "hbm_view": {"algorithmic_bytes_per_launch_avg": act_bytes * rf / n_launch,
+                                 "achieved_GBs": round(act_bytes * rf / (dom_ms_step * 1e-3) / 1e9, 1),
+                                 "frac_of_hbm_peak": round(act_bytes * rf / (dom_ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "note": "the same launches against HBM: activations in + out per launch, weights excluded"},
                     "note": "achieved = algorithmic flops (2 x MACs of the Linear layers x row-frames, fp32 semantics) / launch time; "
                             "HIP events on the launch stream over the timed region"}
         dp_ms = sum(per_step.get(k, 0.0) for k in ("band_lstm", "band_fc", "time_lstm", "time_fc"))

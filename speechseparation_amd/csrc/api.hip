@@ -831,10 +831,14 @@ int bsrnn_commit_params(bsrnn_ctx* c)
                 cost += (long)d.L[l].K16 * d.L[l].NTL;
             }
             const int img = 2 * units * 512;                                  // bytes of one row tile's image (both pieces)
-            int RT = 4 * img <= CHAIN_LDS_EX ? 4 : (2 * img <= CHAIN_LDS_EX ? 2 : (img <= CHAIN_LDS_EX ? 1 : 0));
-            while (RT >= 1 && (8 / RT) * CHAIN_CT < maxntl) RT /= 2;
-            if (RT < 1 || nbias * 4 > CHAIN_LDS_BIAS) { fused = false; break; }   // a band too wide for the fused kernel: per-layer flow
-            d.RT = RT; d.NW = 8 / RT; d.plane_units = units; d.nbias = nbias;
+            // geometry (mlp_chain.hip): RT row tiles per wave group (each weight fragment is used for all of them), GR groups
+            int RT = 0, GR = 1;
+            if (4 * img <= CHAIN_LDS_EX && maxntl <= 6) { RT = 1; GR = 4; }          // narrow: four groups of two waves
+            else if (4 * img <= CHAIN_LDS_EX && maxntl <= 12) { RT = 2; GR = 2; }    // two groups of four waves, two row tiles each
+            else if (2 * img <= CHAIN_LDS_EX) { RT = 2; GR = 1; }
+            else if (img <= CHAIN_LDS_EX) { RT = 1; GR = 1; }
+            if (RT < 1 || (8 / GR) * CHAIN_CT < maxntl || nbias * 4 > CHAIN_LDS_BIAS) { fused = false; break; }   // a band too wide for the fused kernel: per-layer flow
+            d.RT = RT; d.NW = 8 / GR; d.plane_units = units; d.nbias = nbias;
             d.in_off = ch == CHAIN_SPLIT ? c->poff[i] : i * H;
             d.K0 = ch == CHAIN_SPLIT ? round8(a) : H;
             std::vector<uint16_t> stream;
@@ -856,12 +860,14 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         if (!fused) break;
         // class = rows per workgroup (RT = 1, 2, 4, constant bands), heaviest band first inside a class
         std::stable_sort(built.begin(), built.end(), [](const Built& x, const Built& y) {
-            const int cx = x.d.constant ? 3 : (x.d.RT == 1 ? 0 : (x.d.RT == 2 ? 1 : 2)), cy = y.d.constant ? 3 : (y.d.RT == 1 ? 0 : (y.d.RT == 2 ? 1 : 2));
+            auto cls = [](const ChainDesc& d) { const int rows = 4 * d.RT * (8 / d.NW); return d.constant ? 3 : (rows == 4 ? 0 : (rows == 8 ? 1 : 2)); };
+            const int cx = cls(x.d), cy = cls(y.d);
             return cx != cy ? cx < cy : x.cost > y.cost;
         });
         memset(c->chain_ncls[ch], 0, sizeof c->chain_ncls[ch]);
         for (const Built& bu : built) {
-            ++c->chain_ncls[ch][bu.d.constant ? 3 : (bu.d.RT == 1 ? 0 : (bu.d.RT == 2 ? 1 : 2))];
+            const int rows4 = 4 * bu.d.RT * (8 / bu.d.NW);        // rows per workgroup / 8: 32, 64 or 128 rows
+            ++c->chain_ncls[ch][bu.d.constant ? 3 : (rows4 == 4 ? 0 : (rows4 == 8 ? 1 : 2))];
             chains[ch].push_back(bu.d); ch_w[ch].push_back(bu.w); ch_b[ch].push_back(bu.b);
         }
     }

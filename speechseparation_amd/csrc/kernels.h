@@ -64,8 +64,8 @@ constexpr int GEMM_BM = 128;
 // MaskEstimation (bsrnn.py:420-443); intermediates stay in LDS as fp16x2 pieces.
 constexpr int CHAIN_LAYERS = 5;
 constexpr int CHAIN_CT = 3;                   // feature tiles (32 wide) per wave and layer, at most
-constexpr int CHAIN_LDS_EX = 96 * 1024;       // activation images of the workgroup's row tiles
-constexpr int CHAIN_LDS_BIAS = 16 * 1024;     // the chain's biases
+constexpr int CHAIN_LDS_EX = 144 * 1024;      // activation images of the workgroup's row tiles
+constexpr int CHAIN_LDS_BIAS = 13 * 1024;     // the chain's biases (both together: 157 of the CU's 160 KB)
 enum { CHAIN_SPLIT = 0, CHAIN_MASK = 1 };
 struct ChainLayer {
     int K16;             // k-steps of 16 (input width rounded up)
@@ -76,10 +76,10 @@ struct ChainLayer {
 };
 struct ChainDesc {
     ChainLayer L[CHAIN_LAYERS];
-    const void* wstream; // per layer, per wave wn: for ks, for tile t = wn + NW c, for piece: 64 lanes x 8 fp16 (split_host.h)
+    const void* wstream; // per layer, per wave wn: for tile t = wn + NW c, for ks, for piece: 64 lanes x 8 fp16 (split_host.h)
     const float* bias;   // the five bias vectors, each padded with zeros to NTL * 32 (constant band: the constant itself)
     int nbias;
-    int NW, RT;          // waves per row tile, row tiles (of 32 rows) per workgroup; NW * RT = 8
+    int NW, RT;          // NW = 8 waves share the feature tiles; RT = 1, 2, 4 row tiles (of 32 rows) per workgroup
     int plane_units;     // 512-byte units of one piece of one row tile's activation image: max(2 K16, 4 NTL) over the layers
     int in_off;          // first column of the band inside an input row (SPLIT: spectrum row, MASK: b * 64 of a Z row)
     int K0;              // valid input columns, a multiple of 8 (beyond: zeros)
@@ -99,6 +99,7 @@ struct ChainLaunch {
     float* Y; int ldy;               // MASK: x * mask
     float* tap; int ldt;             // MASK: the mask itself (optional)
     int* range_flag;
+    unsigned long long* dbg;         // measurement only (CHAIN_TRACE builds of tools/chain_bench.hip): per-wave phase stamps
 };
 int chain_blocks(const ChainLaunch& g);
 void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);

@@ -21,9 +21,13 @@
 // So a layer is: K loop without barriers or staging (weights in flight in registers, activations static in LDS), barrier,
 // epilogue (bias, LeakyReLU, split, LDS image of the next layer's input [+ P to HBM]), barrier.
 //
-// Geometry: 8 waves per workgroup as RT row tiles x NW waves; a row tile is 32 frame rows (the MFMA's N), its NW waves
-// own the feature tiles t = wn, wn + NW, ... (at most CT = 3 each).  LDS holds rows x Kmax x 4 bytes, so
-//   bands up to 768 columns: NW = 8, RT = 1 (32 rows, 96 KB);  up to 384: NW = 4, RT = 2;  up to 192: NW = 2, RT = 4.
+// Geometry: a workgroup = 8 waves in GR groups of NW = 8 / GR; a group owns RT row tiles of 32 frame rows (the MFMA's N),
+// its waves share the feature tiles (t = wn, wn + NW, ...: at most CT = 3 each, worked through one after the other) and
+// each wave multiplies every weight fragment it loads with all RT row tiles of its group.  The K loop of a wide band is
+// bound by what a CU can pull from L2 (~70 GB/s, measured), so rows per weight byte is the lever there, and LDS capacity
+// (rows x Kmax x 4 bytes of activation image) sets it; the narrow bands are latency bound and want their eight waves busy:
+//   bands up to 768 columns: RT 1, GR 1 ( 32 rows, 96 KB image);   up to 544: RT 2, GR 1 ( 64 rows, shared weights);
+//   up to 288: RT 2, GR 2 (128 rows, two groups of 4 waves);        up to 192: RT 1, GR 4 (128 rows, four groups of 2 waves).
 // One launch per chain; tasks (band, row block) in longest-first order.
 #include "kernels.h"
 
@@ -43,9 +47,21 @@ typedef const h8 __attribute__((address_space(1)))* gch8;
 typedef const char __attribute__((address_space(1)))* gcc;
 
 #ifndef CHAIN_PD
-#define CHAIN_PD 3                 // k-steps of weight fragments in flight per wave (register sets)
+#define CHAIN_PD 8                 // k-steps of weight fragments in flight per wave (register sets of 2 fragments)
 #endif
 constexpr int PD = CHAIN_PD;
+// measurement only (tools/ab_chain_pd.sh): 1 = no MFMAs (operands kept alive), 2 = no weight loads after a tile's first PD steps,
+// 4 = no activation fragment reads after a tile's first; results are wrong by construction
+#ifndef CHAIN_ABL
+#define CHAIN_ABL 0
+#endif
+// measurement only (tools/chain_bench.hip): 100 MHz stamps at the phase boundaries of every wave of the first workgroups
+#ifndef CHAIN_TRACE
+#define CHAIN_TRACE 0
+#endif
+#ifndef CHAIN_PRIO
+#define CHAIN_PRIO 0
+#endif
 
 __device__ __forceinline__ void split4(const v4f a, h4& p0, h4& p1)
 {
@@ -56,195 +72,335 @@ __device__ __forceinline__ void split4(const v4f a, h4& p0, h4& p1)
     for (int i = 0; i < 4; ++i) p1[i] = (_Float16)__builtin_fmaf(-(float)p0[i], 2048.f, a[i] * 2048.f);
 }
 
+// The body of one workgroup: GR groups of NW = 8 / GR waves; a group owns RT row tiles (compile-time: they size the
+// accumulators) and its waves share the feature tiles.  Rows per workgroup = 32 RT GR.
+template <int CHAIN, int TERMS, int RT, int GR>
+__device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc* const dp, const int row0, char* const smem_all)
+{
+    constexpr int NPL = TERMS == 1 ? 1 : 2;       // pieces per operand
+    constexpr int NW = 8 / GR;
+    // prefetch depth: register sets of weight fragments in flight (fewer where two row tiles' accumulators take the room)
+    constexpr int PDR = RT == 1 ? PD : (PD < 4 ? PD : 4);
+    constexpr int CTR = CHAIN_CT;                 // feature tiles per wave and layer, at most
+    float* const sbias = reinterpret_cast<float*>(smem_all + CHAIN_LDS_EX);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave / NW, wn = wave - grp * NW;
+    const int m = lane & 31, h = lane >> 5;
+    const int M = g.M;
+    int row[RT];
+    bool row_ok[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int rr = row0 + 32 * (grp * RT + r) + m;
+        row_ok[r] = rr < M;
+        row[r] = row_ok[r] ? rr : M - 1;
+    }
+
+    unsigned long long tstamp[4 + 3 * CHAIN_LAYERS];
+    int nstamp = 0;
+    auto stamp = [&]() { if (CHAIN_TRACE) tstamp[nstamp++] = __builtin_amdgcn_s_memrealtime(); };
+    stamp();
+    const int plane = dp->plane_units * 512;                     // bytes of one piece of one row tile
+    const int img = NPL * plane;                                 // bytes of one row tile's activation image
+    char* const smem = smem_all + grp * RT * img;                // this group's row tiles
+    float amax = 0.f;
+
+    // weight fragments in flight: register set s holds a k-step of the wave's current tile.  The sets are filled for a layer's
+    // first steps while the previous layer is still in its epilogue and barriers (and for layer 0 before the input is staged)
+    constexpr int STEP = NPL * 1024;                             // bytes of one k-step of one tile: a fragment per piece
+    const gcc wbase = (gcc)dp->wstream;
+    const unsigned lane16 = lane * 16;
+    h8 w[PDR][NPL];
+    auto wload = [&](int set, gcc p) {
+#pragma unroll
+        for (int pc = 0; pc < NPL; ++pc) w[set][pc] = *(gch8)(p + pc * 1024 + lane16);
+    };
+    // tiles of this wave in layer l: t = wn + NW c < NTL; its fragment stream (tile by tile, k-step by k-step) starts behind
+    // those of the waves before it.  (Wave-uniform base + 32-bit lane offset: saddr + voffset loads.)
+    auto layer_stream = [&](int l, int& K16, int& cnt, gcc& wp) {
+        K16 = dp->L[l].K16;
+        const int NTL = dp->L[l].NTL;
+        const int full = NTL / NW, rem = NTL - full * NW;
+        cnt = full + (wn < rem ? 1 : 0);
+        const int before = wn * full + (wn < rem ? wn : rem);
+        wp = wbase + dp->L[l].w_off + (size_t)before * K16 * STEP;
+    };
+    auto prefetch_layer = [&](int l) {
+        int K16, cnt; gcc wp;
+        layer_stream(l, K16, cnt, wp);
+        if (cnt > 0) {
+#pragma unroll
+            for (int s = 0; s < PDR; ++s)
+                if (s < K16) wload(s, wp + (size_t)s * STEP);
+        }
+    };
+    prefetch_layer(0);
+#if CHAIN_PRIO
+    // waves 4-7 are dispatched second and lose every arbitration against their SIMD partner (measured: 33 vs 28 us per
+    // layer of the 768-wide band): one static priority raise for that half (cdna guide, T5 static form)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+
+    // ---- biases of the five layers -> LDS; input rows -> LDS (split on the way), several loads in flight per lane
+    {
+        const gcf bsrc = (gcf)dp->bias;
+        const int nb = dp->nbias;
+        for (int i = tid; i < nb; i += 512) sbias[i] = bsrc[i];
+        const int U0 = 2 * dp->L[0].K16, K0 = dp->K0;
+        constexpr int IB = 8 / RT;                               // units per batch and row tile: 8 float4 in flight per lane
+        for (int u0 = wn; u0 < U0; u0 += NW * IB) {      // (the group's waves share the units)
+            v4f v[RT][IB];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const gcf xin = (gcf)g.Xin + (size_t)row[r] * g.ldx + dp->in_off;
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    const int k = 8 * (u0 + NW * i) + 4 * h;
+                    v[r][i] = (v4f){0.f, 0.f, 0.f, 0.f};
+                    if (k < K0) v[r][i] = *(gc4)(xin + k);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    const int u = u0 + NW * i;
+                    if (u >= U0) continue;
+                    const v4f x = v[r][i];
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+                    h4 p0, p1;
+                    split4(x, p0, p1);
+                    *reinterpret_cast<h4*>(smem + r * img + u * 512 + m * 16 + 8 * h) = p0;
+                    if (NPL == 2) *reinterpret_cast<h4*>(smem + r * img + plane + u * 512 + m * 16 + 8 * h) = p1;
+                }
+        }
+    }
+    stamp();
+    __syncthreads();
+    stamp();
+
+    // one layer; LAST (the chain's fifth layer: global stores instead of an LDS image) is a compile-time property so that the
+    // registers of the two kinds of epilogue (held tiles / prefetched residual and multiplier rows) never coexist
+    auto layer = [&](auto last_tag, const int l) {
+        constexpr bool last = decltype(last_tag)::value;
+        int K16, cnt; gcc wp;
+        layer_stream(l, K16, cnt, wp);
+        const int boff = dp->L[l].bias_off;
+        const bool leaky = dp->L[l].leaky != 0;
+        const bool to_p = CHAIN == CHAIN_SPLIT && l == 1;
+
+        // The K loop is bound by the CU's fill rate from L2 (~70 GB/s per CU, measured: tools/chain_bench.hip), so every
+        // weight fragment a wave loads is multiplied with all RT row tiles of its group.  The wave works through its tiles one after the other: one accumulator pair per row tile, and PDR k-steps of
+        // weight fragments in flight.  A finished tile cannot go to the LDS image yet (other waves are still reading the
+        // layer's input from it), so it is kept split, as fp16 pieces, until the barrier.  Register set s holds k-step
+        // ks0 + s; it is refilled right behind the MFMAs that consumed it, with the step PDR further on, or with the NEXT
+        // tile's step s when this tile has no such step.
+        h4 held[last ? 1 : CTR][RT][4][NPL];
+#pragma unroll
+        for (int c = 0; c < CTR; ++c) {
+            if (c >= cnt) break;
+            const int t = wn + NW * c;
+            const gcc tp = wp + (size_t)c * K16 * STEP;
+            const bool more = c + 1 < cnt;
+            // the last layer of the mask chain also needs the residual and the spectrum it multiplies: in flight during the K
+            // loop where the registers allow it (RT <= 2)
+            constexpr bool PRE_RM = CHAIN == CHAIN_MASK && last && RT <= 2;     // (no held tiles in the last layer)
+            v4f rv[PRE_RM ? RT : 1][4], mv[PRE_RM ? RT : 1][4];
+            if (PRE_RM) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int n0 = 32 * t + 8 * q + 4 * h;
+                        n0 = n0 < dp->a8 ? n0 : 0;
+                        rv[r][q] = *(gc4)((gcf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0);
+                        mv[r][q] = *(gc4)((gcf)g.Xmul + (size_t)row[r] * g.ldm + dp->p_off + n0);
+                    }
+            }
+            v16f hi[RT], lo[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) { hi[r] = (v16f){0}; lo[r] = (v16f){0}; }
+            // activation fragments one k-step ahead of the MFMAs where the registers allow it (the fences below would
+            // otherwise leave every ds_read right in front of its consumer: one exposed LDS latency per MFMA)
+            constexpr bool BAHEAD = RT == 1;
+            h8 bn[RT][NPL];
+            auto bload = [&](int ks) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int pc = 0; pc < NPL; ++pc) bn[r][pc] = *reinterpret_cast<const h8*>(smem + r * img + pc * plane + ks * 1024 + lane * 16);
+            };
+            if (BAHEAD) bload(0);
+            auto compute = [&](int set, int ks) {
+                h8 b[RT][NPL];
+                if (BAHEAD) {
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int pc = 0; pc < NPL; ++pc) b[r][pc] = bn[r][pc];
+                    if (!(CHAIN_ABL & 4)) bload(ks + 1 < K16 ? ks + 1 : ks);
+                } else {
+                    // two row tiles' accumulators leave no room for fragments in flight: read them one row tile at a time, right
+                    // in front of their MFMAs (the SIMD's other wave covers the LDS latency)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+#pragma unroll
+                        for (int pc = 0; pc < NPL; ++pc) b[r][pc] = *reinterpret_cast<const h8*>(smem + r * img + pc * plane + ks * 1024 + lane * 16);
+                        if (r + 1 < RT) __builtin_amdgcn_sched_barrier(0);
+                        if (NPL == 2) {
+                            lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][0], b[r][NPL - 1], lo[r], 0, 0, 0);
+                            lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][NPL - 1], b[r][0], lo[r], 0, 0, 0);
+                        }
+                        hi[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][0], b[r][0], hi[r], 0, 0, 0);
+                        if (r + 1 < RT) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    return;
+                }
+                if (CHAIN_ABL & 1) {
+                    asm volatile("" ::"v"(w[set][0]), "v"(w[set][NPL - 1]), "v"(b[0][0]), "v"(b[RT - 1][NPL - 1]));
+                    return;
+                }
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (NPL == 2) {
+                        lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][0], b[r][NPL - 1], lo[r], 0, 0, 0);      // w1 x2
+                        lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][NPL - 1], b[r][0], lo[r], 0, 0, 0);      // w2 x1
+                    }
+                    hi[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][0], b[r][0], hi[r], 0, 0, 0);                // w1 x1
+                }
+            };
+            int ks0 = 0;
+            for (; ks0 + 2 * PDR <= K16; ks0 += PDR) {           // steady state: branch-free
+#pragma unroll
+                for (int s = 0; s < PDR; ++s) {
+                    // (left alone, hipcc sinks all the loads of an iteration to its end and waits for them at the top of the
+                    // next: no run-ahead at all; the fence keeps each refill behind its own step)
+                    compute(s, ks0 + s);
+                    if (!(CHAIN_ABL & 2)) wload(s, tp + (size_t)(ks0 + s + PDR) * STEP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            for (; ks0 < K16; ks0 += PDR) {                      // the last groups of the tile; refills cross into the next tile
+#pragma unroll
+                for (int s = 0; s < PDR; ++s) {
+                    const int ks = ks0 + s;
+                    if (ks < K16) {
+                        compute(s, ks);
+                        if (ks + PDR < K16) wload(s, tp + (size_t)(ks + PDR) * STEP);
+                        else if (more && s < K16) wload(s, tp + (size_t)(K16 + s) * STEP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+
+            // ---- the tile's epilogue: bias, LeakyReLU, then either global stores (last layer; P) or the split pieces
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n0 = 32 * t + 8 * q + 4 * h;       // first of this lane's 4 consecutive features
+                    const v4f bv = *reinterpret_cast<const v4f*>(&sbias[boff + n0]);
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sum = TERMS == 1 ? hi[r][4 * q + e] : hi[r][4 * q + e] + (1.f / 2048.f) * lo[r][4 * q + e];
+                        v[e] = sum + bv[e];
+                        if (leaky) v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                    }
+                    if (!last) {
+                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+                        h4 p0, p1;
+                        split4(v, p0, p1);
+                        held[last ? 0 : c][r][q][0] = p0;
+                        held[last ? 0 : c][r][q][NPL - 1] = NPL == 2 ? p1 : p0;
+                        if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0) = v;
+                    } else if (CHAIN == CHAIN_SPLIT) {
+                        if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)row[r] * g.ldz + dp->z_off + n0) = v;
+                    } else {
+                        if (row_ok[r] && n0 < dp->a8) {
+                            const v4f rr = PRE_RM ? rv[PRE_RM ? r : 0][q] : *(gc4)((gcf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0);
+                            const v4f mm = PRE_RM ? mv[PRE_RM ? r : 0][q] : *(gc4)((gcf)g.Xmul + (size_t)row[r] * g.ldm + dp->p_off + n0);
+                            v += rr;                                                 // mask = residual + post(...)   bsrnn.py:425
+                            if (g.tap) *(g4)((gf)g.tap + (size_t)row[r] * g.ldt + dp->p_off + n0) = v;
+                            *(g4)((gf)g.Y + (size_t)row[r] * g.ldy + dp->p_off + n0) = v * mm;   // x * mask      bsrnn.py:441
+                        }
+                    }
+                }
+        }
+        // the next layer's first fragments: in flight across the barriers; where two row tiles' held pieces fill the
+        // registers (RT = 2), only once those have gone to LDS
+        constexpr bool XPRE = RT == 1;
+        if (!last && XPRE) prefetch_layer(l + 1);
+        stamp();
+        if (last) return;
+        __syncthreads();                                         // every wave has read the layer's input image
+        stamp();
+#pragma unroll
+        for (int c = 0; c < CTR; ++c) {
+            if (c >= cnt) break;
+            const int t = wn + NW * c;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int u = 4 * t + q;
+                    *reinterpret_cast<h4*>(smem + r * img + u * 512 + m * 16 + 8 * h) = held[last ? 0 : c][r][q][0];
+                    if (NPL == 2) *reinterpret_cast<h4*>(smem + r * img + plane + u * 512 + m * 16 + 8 * h) = held[last ? 0 : c][r][q][NPL - 1];
+                }
+        }
+        if (!XPRE) prefetch_layer(l + 1);
+        __syncthreads();                                         // the next layer's input image is complete
+        stamp();
+    };
+#pragma unroll 1
+    for (int l = 0; l < CHAIN_LAYERS - 1; ++l) layer(std::false_type(), l);
+    layer(std::true_type(), CHAIN_LAYERS - 1);
+
+    if (CHAIN_TRACE && g.dbg && lane == 0 && blockIdx.x < 64) {
+        unsigned long long* d = g.dbg + ((size_t)blockIdx.x * 8 + wave) * 24;
+        for (int i = 0; i < nstamp && i < 24; ++i) d[i] = tstamp[i];
+    }
+    // range guard (see gemm.hip): a finite operand beyond the fp16 range saturated its first piece
+    if (amax > 65504.f && g.range_flag) *g.range_flag = 1;
+}
+
 template <int CHAIN, int TERMS>
 __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
 {
-    constexpr int NPL = TERMS == 1 ? 1 : 2;       // pieces per operand
     __shared__ __attribute__((aligned(16))) char smem[CHAIN_LDS_EX + CHAIN_LDS_BIAS];
-    float* const sbias = reinterpret_cast<float*>(smem + CHAIN_LDS_EX);
 
     // block -> (band, first row): classes of 32 / 64 / 128 / 256 rows per workgroup, class by class, band by band
-    int bid = blockIdx.x, di = 0, row0 = 0;
+    int bid = blockIdx.x, di = 0, row0 = 0, cls = 0;
     {
         int rows = 32;
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl, rows *= 2) {
             const int nblk = (g.M + rows - 1) / rows, ncl = g.n_cls[cl] * nblk;
-            if (bid < ncl || cl == 3) { di += bid / nblk; row0 = (bid - (bid / nblk) * nblk) * rows; break; }
+            if (bid < ncl || cl == 3) { di += bid / nblk; row0 = (bid - (bid / nblk) * nblk) * rows; cls = cl; break; }
             bid -= ncl; di += g.n_cls[cl];
         }
     }
     const ChainDesc* const dp = g.desc + di;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = dp->NW;
-    const int rt = wave / NW, wn = wave - rt * NW;
-    const int m = lane & 31, h = lane >> 5;
-    const int M = g.M;
-    const int row_raw = row0 + 32 * rt + m;
-    const bool row_ok = row_raw < M;
-    const int row = row_ok ? row_raw : M - 1;
-
-    if (CHAIN == CHAIN_SPLIT && dp->constant) {
+    if (cls == 3) {
         // TrainableConstantModule (bsrnn.py:12-24): the zero-width band's feature is one learned vector for every frame
-        const gcf cst = (gcf)dp->bias;
-        for (int i = tid; i < 32 * 8 * 16; i += 512) {           // 256 rows x 16 float4
-            const int r = row0 + (i >> 4), c4 = i & 15;
-            if (r < M) *(g4)((gf)g.Z + (size_t)r * g.ldz + dp->z_off + 4 * c4) = *(gc4)(cst + 4 * c4);
+        if (CHAIN == CHAIN_SPLIT) {
+            const gcf cst = (gcf)dp->bias;
+            for (int i = threadIdx.x; i < 256 * 16; i += 512) {  // 256 rows x 16 float4
+                const int r = row0 + (i >> 4), c4 = i & 15;
+                if (r < g.M) *(g4)((gf)g.Z + (size_t)r * g.ldz + dp->z_off + 4 * c4) = *(gc4)(cst + 4 * c4);
+            }
         }
         return;
     }
-
-    const int plane = dp->plane_units * 512;                     // bytes of one piece of one row tile
-    char* const ex = smem + rt * NPL * plane;                    // this row tile's activation image
-    float amax = 0.f;
-
-    // ---- biases of the five layers -> LDS; input rows -> LDS (split on the way)
-    {
-        const gcf bsrc = (gcf)dp->bias;
-        const int nb = dp->nbias;
-        for (int i = tid; i < nb; i += 512) sbias[i] = bsrc[i];
-        const gcf xin = (gcf)g.Xin + (size_t)row * g.ldx + dp->in_off;
-        const int U0 = 2 * dp->L[0].K16, K0 = dp->K0;
-        for (int u = wn; u < U0; u += NW) {
-            const int k = 8 * u + 4 * h;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (k < K0) v = *(gc4)(xin + k);
-            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
-            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
-            h4 p0, p1;
-            split4(v, p0, p1);
-            *reinterpret_cast<h4*>(ex + u * 512 + m * 16 + 8 * h) = p0;
-            if (NPL == 2) *reinterpret_cast<h4*>(ex + plane + u * 512 + m * 16 + 8 * h) = p1;
-        }
-    }
-    __syncthreads();
-
-    const gcc wbase = (gcc)dp->wstream;
-#pragma unroll 1
-    for (int l = 0; l < CHAIN_LAYERS; ++l) {
-        const int K16 = dp->L[l].K16, NTL = dp->L[l].NTL;
-        // tiles of this wave: t = wn + NW c < NTL; its fragment stream starts behind those of the waves before it
-        const int full = NTL / NW, rem = NTL - full * NW;
-        const int cnt = full + (wn < rem ? 1 : 0);
-        const int before = wn * full + (wn < rem ? wn : rem);
-        const gcc wp = wbase + dp->L[l].w_off + ((size_t)before * K16 * NPL << 10) + lane * 16;
-
-        v16f hi[CHAIN_CT], lo[CHAIN_CT];
-#pragma unroll
-        for (int c = 0; c < CHAIN_CT; ++c) { hi[c] = (v16f){0}; lo[c] = (v16f){0}; }
-
-        // ---- K loop: no barriers, no staging.  PD register sets of weight fragments in flight.
-        auto kloop = [&](auto cnt_tag) {
-            constexpr int CNT = decltype(cnt_tag)::value;
-            constexpr int STEP = CNT * NPL * 1024;               // bytes of one k-step of this wave's stream
-            h8 w[PD][CNT][NPL];
-            auto wload = [&](int set, int ks) {
-                const gcc p = wp + (size_t)ks * STEP;
-#pragma unroll
-                for (int c = 0; c < CNT; ++c)
-#pragma unroll
-                    for (int pc = 0; pc < NPL; ++pc) w[set][c][pc] = *(gch8)(p + (c * NPL + pc) * 1024);
-            };
-            auto compute = [&](int set, int ks) {
-                const h8 b0 = *reinterpret_cast<const h8*>(ex + ks * 1024 + lane * 16);
-                h8 b1 = b0;
-                if (NPL == 2) b1 = *reinterpret_cast<const h8*>(ex + plane + ks * 1024 + lane * 16);
-#pragma unroll
-                for (int c = 0; c < CNT; ++c) {
-                    if (NPL == 2) {
-                        lo[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][c][0], b1, lo[c], 0, 0, 0);          // w1 x2
-                        lo[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][c][NPL - 1], b0, lo[c], 0, 0, 0);    // w2 x1
-                    }
-                    hi[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][c][0], b0, hi[c], 0, 0, 0);              // w1 x1
-                }
-            };
-#pragma unroll
-            for (int s = 0; s < PD; ++s)
-                if (s < K16) wload(s, s);
-            int ks0 = 0;
-            for (; ks0 + 2 * PD <= K16; ks0 += PD) {             // steady state: branch-free
-#pragma unroll
-                for (int s = 0; s < PD; ++s) {
-                    // the refill of a register set goes right behind the MFMAs that consumed it (left alone, hipcc sinks all
-                    // the loads of an iteration to its end and waits for them at the top of the next: no run-ahead at all)
-                    compute(s, ks0 + s);
-                    wload(s, ks0 + s + PD);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            for (; ks0 < K16; ks0 += PD) {
-#pragma unroll
-                for (int s = 0; s < PD; ++s) {
-                    if (ks0 + s < K16) {
-                        compute(s, ks0 + s);
-                        if (ks0 + s + PD < K16) wload(s, ks0 + s + PD);
-                    }
-                }
-            }
-        };
-        if (cnt == 3) kloop(std::integral_constant<int, 3>());
-        else if (cnt == 2) kloop(std::integral_constant<int, 2>());
-        else if (cnt == 1) kloop(std::integral_constant<int, 1>());
-
-        __syncthreads();                                         // every wave has read the layer's input image
-
-        // ---- epilogue
-        const int boff = dp->L[l].bias_off;
-        const bool leaky = dp->L[l].leaky != 0;
-        const bool last = l == CHAIN_LAYERS - 1;
-        const bool to_p = CHAIN == CHAIN_SPLIT && l == 1;
-#pragma unroll
-        for (int c = 0; c < CHAIN_CT; ++c) {
-            if (c >= cnt) break;
-            __builtin_amdgcn_sched_barrier(0);                   // one tile at a time: keeps the epilogue's registers bounded
-            const int t = wn + NW * c;
-            // the last layer of the mask chain also needs the residual and the spectrum it multiplies: requested up front
-            v4f rv[4], mv[4];
-            if (CHAIN == CHAIN_MASK && last) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int n0 = 32 * t + 8 * q + 4 * h;
-                    n0 = n0 < dp->a8 ? n0 : 0;
-                    rv[q] = *(gc4)((gcf)g.P + (size_t)row * g.ldp + dp->p_off + n0);
-                    mv[q] = *(gc4)((gcf)g.Xmul + (size_t)row * g.ldm + dp->p_off + n0);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n0 = 32 * t + 8 * q + 4 * h;           // first of this lane's 4 consecutive features
-                const v4f bv = *reinterpret_cast<const v4f*>(&sbias[boff + n0]);
-                v4f v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float s = TERMS == 1 ? hi[c][4 * q + e] : hi[c][4 * q + e] + (1.f / 2048.f) * lo[c][4 * q + e];
-                    v[e] = s + bv[e];
-                    if (leaky) v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
-                }
-                if (!last) {
-                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
-                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
-                    h4 p0, p1;
-                    split4(v, p0, p1);
-                    const int u = 4 * t + q;
-                    *reinterpret_cast<h4*>(ex + u * 512 + m * 16 + 8 * h) = p0;
-                    if (NPL == 2) *reinterpret_cast<h4*>(ex + plane + u * 512 + m * 16 + 8 * h) = p1;
-                    if (to_p && row_ok && n0 < dp->a8) *(g4)((gf)g.P + (size_t)row * g.ldp + dp->p_off + n0) = v;
-                } else if (CHAIN == CHAIN_SPLIT) {
-                    if (row_ok && n0 < HID) *(g4)((gf)g.Z + (size_t)row * g.ldz + dp->z_off + n0) = v;
-                } else {
-                    if (row_ok && n0 < dp->a8) {
-                        v += rv[q];                                                  // mask = residual + post(...)   bsrnn.py:425
-                        if (g.tap) *(g4)((gf)g.tap + (size_t)row * g.ldt + dp->p_off + n0) = v;
-                        *(g4)((gf)g.Y + (size_t)row * g.ldy + dp->p_off + n0) = v * mv[q];   // x * mask          bsrnn.py:441
-                    }
-                }
-            }
-        }
-        __syncthreads();                                         // the next layer's input image is complete
-    }
-    // range guard (see gemm.hip): a finite operand beyond the fp16 range saturated its first piece
-    if (amax > 65504.f && g.range_flag) *g.range_flag = 1;
+    // geometry of the workgroup (wave-uniform): rows = 32 RT GR
+    const int RT = dp->RT, GR = 8 / dp->NW;
+    if (RT == 1 && GR == 1) chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem);
+    else if (RT == 2 && GR == 1) chain_body<CHAIN, TERMS, 2, 1>(g, dp, row0, smem);
+    else if (RT == 2 && GR == 2) chain_body<CHAIN, TERMS, 2, 2>(g, dp, row0, smem);
+    else chain_body<CHAIN, TERMS, 1, 4>(g, dp, row0, smem);
 }
 
 int chain_blocks(const ChainLaunch& g)

@@ -79,14 +79,14 @@ inline void pack_h2_slabs_host(const float* w, int N, int K, int ldw, int K32, i
 
 // Fragment streams of one Linear layer for the fused chain kernel (mlp_chain.hip): the weights are the MFMA's A operand
 // (v_mfma_f32_32x32x16_f16: lane (r = l & 31, h = l >> 5) holds W[32 t + r][16 ks + 8 h + j], j < 8) and every wave of a
-// row tile walks its own linear stream: for wave wn of NW, for k-step ks, for its tiles t = wn, wn + NW, ..., for piece
+// row tile walks its own linear stream: for wave wn of NW, for its tiles t = wn, wn + NW, ..., for k-step ks, for piece
 // (npl = 2: fp16x2, 1: plain fp16): 64 lanes x 8 halves = 1 KB.  Rows >= N and columns >= K are zeros.  Appends to `out`.
 inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out)
 {
     const int K16 = (K + 15) / 16, NTL = (N + 31) / 32;
     for (int wn = 0; wn < NW; ++wn)
-        for (int ks = 0; ks < K16; ++ks)
-            for (int t = wn; t < NTL; t += NW)
+        for (int t = wn; t < NTL; t += NW)
+            for (int ks = 0; ks < K16; ++ks)
                 for (int pc = 0; pc < npl; ++pc)
                     for (int l = 0; l < 64; ++l)
                         for (int j = 0; j < 8; ++j) {
