@@ -809,7 +809,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             if (a == 0) {
                 if (ch != CHAIN_SPLIT) continue;
                 snprintf(b, sizeof b, "bandFCs.%d.0.trainable_constant", i);
-                d.constant = 1; d.NW = 8; d.RT = 1; d.nbias = H;
+                d.constant = 1; d.NW = 1; d.RT = 1; d.nbias = H;     // (a 256-row class member, like the GR = 8 geometry)
                 bu.w = 0; bu.b = ar.put(P_(c, b).data); bu.cost = -1;
                 built.push_back(bu);
                 continue;
@@ -833,7 +833,8 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             const int img = 2 * units * 512;                                  // bytes of one row tile's image (both pieces)
             // geometry (mlp_chain.hip): RT row tiles per wave group (each weight fragment is used for all of them), GR groups
             int RT = 0, GR = 1;
-            if (4 * img <= CHAIN_LDS_EX && maxntl <= 6) { RT = 1; GR = 4; }          // narrow: four groups of two waves
+            if (8 * img <= CHAIN_LDS_EX && maxntl <= 4) { RT = 1; GR = 8; }          // narrowest: every wave a chain of its own
+            else if (4 * img <= CHAIN_LDS_EX && maxntl <= 6) { RT = 1; GR = 4; }     // narrow: four groups of two waves
             else if (4 * img <= CHAIN_LDS_EX && maxntl <= 12) { RT = 2; GR = 2; }    // two groups of four waves, two row tiles each
             else if (2 * img <= CHAIN_LDS_EX) { RT = 2; GR = 1; }
             else if (img <= CHAIN_LDS_EX) { RT = 1; GR = 1; }
@@ -860,14 +861,14 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         if (!fused) break;
         // class = rows per workgroup (RT = 1, 2, 4, constant bands), heaviest band first inside a class
         std::stable_sort(built.begin(), built.end(), [](const Built& x, const Built& y) {
-            auto cls = [](const ChainDesc& d) { const int rows = 4 * d.RT * (8 / d.NW); return d.constant ? 3 : (rows == 4 ? 0 : (rows == 8 ? 1 : 2)); };
+            auto cls = [](const ChainDesc& d) { const int rows = 4 * d.RT * (8 / d.NW); return d.constant ? 4 : (rows == 4 ? 0 : (rows == 8 ? 1 : (rows == 16 ? 2 : 3))); };
             const int cx = cls(x.d), cy = cls(y.d);
             return cx != cy ? cx < cy : x.cost > y.cost;
         });
         memset(c->chain_ncls[ch], 0, sizeof c->chain_ncls[ch]);
         for (const Built& bu : built) {
             const int rows4 = 4 * bu.d.RT * (8 / bu.d.NW);        // rows per workgroup / 8: 32, 64 or 128 rows
-            ++c->chain_ncls[ch][bu.d.constant ? 3 : (rows4 == 4 ? 0 : (rows4 == 8 ? 1 : 2))];
+            ++c->chain_ncls[ch][bu.d.constant ? 3 : (rows4 == 4 ? 0 : (rows4 == 8 ? 1 : (rows4 == 16 ? 2 : 3)))];
             chains[ch].push_back(bu.d); ch_w[ch].push_back(bu.w); ch_b[ch].push_back(bu.b);
         }
     }

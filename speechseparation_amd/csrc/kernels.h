@@ -79,7 +79,7 @@ struct ChainDesc {
     const void* wstream; // per layer, per wave wn: for tile t = wn + NW c, for ks, for piece: 64 lanes x 8 fp16 (split_host.h)
     const float* bias;   // the five bias vectors, each padded with zeros to NTL * 32 (constant band: the constant itself)
     int nbias;
-    int NW, RT;          // NW = 8 waves share the feature tiles; RT = 1, 2, 4 row tiles (of 32 rows) per workgroup
+    int NW, RT;          // groups of NW waves share the feature tiles of their RT row tiles (of 32 rows): mlp_chain.hip
     int plane_units;     // 512-byte units of one piece of one row tile's activation image: max(2 K16, 4 NTL) over the layers
     int in_off;          // first column of the band inside an input row (SPLIT: spectrum row, MASK: b * 64 of a Z row)
     int K0;              // valid input columns, a multiple of 8 (beyond: zeros)
@@ -89,8 +89,8 @@ struct ChainDesc {
     int constant;        // zero-width band (TrainableConstantModule, bsrnn.py:12-24): Z[:, z_off .. +64) = bias[0 .. 64)
 };
 struct ChainLaunch {
-    const ChainDesc* desc;   // device array, grouped by class: RT = 1, then 2, then 4, then the constant bands (256 rows per
-    int n_cls[4];            //   workgroup); heaviest band first inside a class.  Blocks = sum n_cls[i] * ceil(M / rows_i).
+    const ChainDesc* desc;   // device array, grouped by class = rows per workgroup (32, 64, 128, 256; the constant bands are in
+    int n_cls[4];            //   the last), heaviest band first inside a class.  Blocks = sum n_cls[i] * ceil(M / rows_i).
     int M;
     const float* Xin; int ldx;       // SPLIT: spectrum rows; MASK: Z rows
     float* P; int ldp;               // SPLIT: written (bandFCs_pre output = the mask's residual); MASK: read

@@ -27,7 +27,8 @@
 // bound by what a CU can pull from L2 (~70 GB/s, measured), so rows per weight byte is the lever there, and LDS capacity
 // (rows x Kmax x 4 bytes of activation image) sets it; the narrow bands are latency bound and want their eight waves busy:
 //   bands up to 768 columns: RT 1, GR 1 ( 32 rows, 96 KB image);   up to 544: RT 2, GR 1 ( 64 rows, shared weights);
-//   up to 288: RT 2, GR 2 (128 rows, two groups of 4 waves);        up to 192: RT 1, GR 4 (128 rows, four groups of 2 waves).
+//   up to 288: RT 2, GR 2 (128 rows, two groups of 4 waves);        up to 192: RT 1, GR 4 (128 rows, four groups of 2 waves);
+//   up to 128: RT 1, GR 8 (256 rows: every wave runs the whole chain of its own row tile, no barriers).
 // One launch per chain; tasks (band, row block) in longest-first order.
 #include "kernels.h"
 
@@ -51,7 +52,7 @@ typedef const char __attribute__((address_space(1)))* gcc;
 #endif
 constexpr int PD = CHAIN_PD;
 // measurement only (tools/ab_chain_pd.sh): 1 = no MFMAs (operands kept alive), 2 = no weight loads after a tile's first PD steps,
-// 4 = no activation fragment reads after a tile's first; results are wrong by construction
+// 4 = no activation fragment reads after a tile's first, 8 = all waves read the same weight stream; results are wrong by construction
 #ifndef CHAIN_ABL
 #define CHAIN_ABL 0
 #endif
@@ -81,7 +82,11 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
     constexpr int NW = 8 / GR;
     // prefetch depth: register sets of weight fragments in flight (fewer where two row tiles' accumulators take the room)
     constexpr int PDR = RT == 1 ? PD : (PD < 4 ? PD : 4);
-    constexpr int CTR = CHAIN_CT;                 // feature tiles per wave and layer, at most
+    constexpr int CTR = GR == 8 ? 4 : CHAIN_CT;   // feature tiles per wave and layer, at most
+    // GR = 8: every wave is a group of its own (one row tile, all feature tiles of the band, layers up to 128 wide): its
+    // activation image is private, so the layer barriers are not needed (a wave's LDS accesses are performed in order)
+    constexpr bool SOLO = GR == 8;
+    auto group_barrier = [&]() { if (!SOLO) __syncthreads(); };
     float* const sbias = reinterpret_cast<float*>(smem_all + CHAIN_LDS_EX);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,7 +128,8 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
         const int NTL = dp->L[l].NTL;
         const int full = NTL / NW, rem = NTL - full * NW;
         cnt = full + (wn < rem ? 1 : 0);
-        const int before = wn * full + (wn < rem ? wn : rem);
+        int before = wn * full + (wn < rem ? wn : rem);
+        if (CHAIN_ABL & 8) before = 0;             // measurement only: every wave streams wave 0's fragments (L1-hot for 7 of 8)
         wp = wbase + dp->L[l].w_off + (size_t)before * K16 * STEP;
     };
     auto prefetch_layer = [&](int l) {
@@ -336,7 +342,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
         if (!last && XPRE) prefetch_layer(l + 1);
         stamp();
         if (last) return;
-        __syncthreads();                                         // every wave has read the layer's input image
+        group_barrier();                                         // every wave has read the layer's input image
         stamp();
 #pragma unroll
         for (int c = 0; c < CTR; ++c) {
@@ -352,7 +358,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                 }
         }
         if (!XPRE) prefetch_layer(l + 1);
-        __syncthreads();                                         // the next layer's input image is complete
+        group_barrier();                                         // the next layer's input image is complete
         stamp();
     };
 #pragma unroll 1
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
         }
     }
     const ChainDesc* const dp = g.desc + di;
-    if (cls == 3) {
+    if (cls == 3 && dp->constant) {
         // TrainableConstantModule (bsrnn.py:12-24): the zero-width band's feature is one learned vector for every frame
         if (CHAIN == CHAIN_SPLIT) {
             const gcf cst = (gcf)dp->bias;
@@ -397,7 +403,8 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
     }
     // geometry of the workgroup (wave-uniform): rows = 32 RT GR
     const int RT = dp->RT, GR = 8 / dp->NW;
-    if (RT == 1 && GR == 1) chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem);
+    if (GR == 8) chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem);
+    else if (RT == 1 && GR == 1) chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem);
     else if (RT == 2 && GR == 1) chain_body<CHAIN, TERMS, 2, 1>(g, dp, row0, smem);
     else if (RT == 2 && GR == 2) chain_body<CHAIN, TERMS, 2, 2>(g, dp, row0, smem);
     else chain_body<CHAIN, TERMS, 1, 4>(g, dp, row0, smem);

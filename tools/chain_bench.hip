@@ -59,7 +59,8 @@ int main(int argc, char** argv)
         }
         const int img = 2 * units * 512;
         int RT = 1, GR = 1;
-        if (4 * img <= CHAIN_LDS_EX && maxntl <= 6) { RT = 1; GR = 4; }
+        if (8 * img <= CHAIN_LDS_EX && maxntl <= 4) { RT = 1; GR = 8; }
+        else if (4 * img <= CHAIN_LDS_EX && maxntl <= 6) { RT = 1; GR = 4; }
         else if (4 * img <= CHAIN_LDS_EX && maxntl <= 12) { RT = 2; GR = 2; }
         else if (2 * img <= CHAIN_LDS_EX) { RT = 2; GR = 1; }
         if (getenv("CHAIN_GEOM")) sscanf(getenv("CHAIN_GEOM"), "%d,%d", &RT, &GR);      // override (must fit the LDS)
@@ -79,7 +80,7 @@ int main(int argc, char** argv)
         built.push_back(std::move(bu));
     }
     std::stable_sort(built.begin(), built.end(), [](const Built& x, const Built& y) {
-        auto cls = [](const ChainDesc& d) { const int r4 = 4 * d.RT * (8 / d.NW); return r4 == 4 ? 0 : (r4 == 8 ? 1 : 2); };
+        auto cls = [](const ChainDesc& d) { const int r4 = 4 * d.RT * (8 / d.NW); return r4 == 4 ? 0 : (r4 == 8 ? 1 : (r4 == 16 ? 2 : 3)); };
         const int cx = cls(x.d), cy = cls(y.d);
         return cx != cy ? cx < cy : x.cost > y.cost;
     });
@@ -91,7 +92,7 @@ int main(int argc, char** argv)
         CK(hipMalloc(&dw, bu.w.size() * 2 + 64)); CK(hipMemcpy(dw, bu.w.data(), bu.w.size() * 2, hipMemcpyHostToDevice));
         CK(hipMalloc(&db, bu.b.size() * 4)); CK(hipMemcpy(db, bu.b.data(), bu.b.size() * 4, hipMemcpyHostToDevice));
         bu.d.wstream = dw; bu.d.bias = (const float*)db;
-        { const int r4 = 4 * bu.d.RT * (8 / bu.d.NW); ++g.n_cls[r4 == 4 ? 0 : (r4 == 8 ? 1 : 2)]; }
+        { const int r4 = 4 * bu.d.RT * (8 / bu.d.NW); ++g.n_cls[r4 == 4 ? 0 : (r4 == 8 ? 1 : (r4 == 16 ? 2 : 3))]; }
         descs.push_back(bu.d);
     }
     ChainDesc* dd;
