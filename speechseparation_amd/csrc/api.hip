@@ -87,7 +87,10 @@ struct bsrnn_ctx {
     // fused per-band MLP chains (mlp_chain.hip): device descriptor arrays, grouped by class (kernels.h, ChainLaunch)
     bool fused = false;             // false: per-layer launches (BSRNN_MLP=layers, fp32 mode, or a band too wide for the LDS image)
     ChainDesc* d_chain[2] = {nullptr, nullptr};
-    int chain_ncls[2][4];
+    std::vector<ChainDesc> h_chain[2];          // host copies (geometry and cost per band: the task tables are made from them)
+    std::vector<long> chain_cost[2];
+    struct TaskTable { int2* d[2]; int n[2]; };
+    std::map<int, TaskTable> chain_tasks;       // per row count M: device task tables of the two chains
 
     const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
     const void *bandW16[2][2], *timeW16[2];
@@ -316,6 +319,44 @@ int ensure_streams(bsrnn_ctx* c, int parts)
     return 0;
 }
 
+// Task table of a fused chain launch for M frame rows: one entry (descriptor, first row) per workgroup, in dispatch order:
+// longest workgroups first (the descriptors are sorted by class and cost at commit), all row blocks of a band together
+// (they share its weight stream through L2).  Measured and dropped: interleaving the fill-bound 768-wide band with the
+// others (its workgroups take 97 us on half the CUs against 129 us on all of them, tools/chain_bench.hip) - the late starts
+// of the long workgroups cost more than the contention saves (310 vs 250 us per chain).
+void build_chain_tasks(const bsrnn_ctx* c, int ch, int M, std::vector<int2>& out)
+{
+    out.clear();
+    const auto& ds = c->h_chain[ch];
+    for (size_t di = 0; di < ds.size(); ++di)
+        for (int r0 = 0; r0 < M; r0 += chain_rows(ds[di])) out.push_back(make_int2((int)di, r0));
+}
+
+int ensure_tasks(bsrnn_ctx* c, int M)
+{
+    if (!c->fused) return 0;
+    auto it = c->chain_tasks.find(M);
+    if (it == c->chain_tasks.end()) {
+        if (c->chain_tasks.size() >= 64) {           // bounded cache: drop everything (captured streaming graphs re-capture)
+            HIP_TRY(hipDeviceSynchronize());
+            for (auto& kv : c->chain_tasks)
+                for (int ch = 0; ch < 2; ++ch) (void)hipFree(kv.second.d[ch]);
+            c->chain_tasks.clear();
+            ++c->gen;
+        }
+        bsrnn_ctx::TaskTable t;
+        std::vector<int2> h;
+        for (int ch = 0; ch < 2; ++ch) {
+            build_chain_tasks(c, ch, M, h);
+            t.n[ch] = (int)h.size();
+            HIP_TRY(hipMalloc((void**)&t.d[ch], (h.size() + 1) * sizeof(int2)));
+            HIP_TRY(hipMemcpy(t.d[ch], h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice));
+        }
+        c->chain_tasks.emplace(M, t);
+    }
+    return 0;
+}
+
 void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ldy, const float* R, int ldr,
                const float* Mul, int ldm, float* tap, int M, int epi, hipStream_t s)
 {
@@ -373,8 +414,8 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         if (c->fused && !force_f32()) {      // all five layers of every band in one launch, intermediates in LDS
             ChainLaunch g;
             memset(&g, 0, sizeof g);
-            g.desc = c->d_chain[CHAIN_SPLIT];
-            memcpy(g.n_cls, c->chain_ncls[CHAIN_SPLIT], sizeof g.n_cls);
+            const bsrnn_ctx::TaskTable& tt = c->chain_tasks.at(M);       // made by ensure_chain_tasks() before any launch (and outside graph capture)
+            g.desc = c->d_chain[CHAIN_SPLIT]; g.tasks = tt.d[CHAIN_SPLIT]; g.n_tasks = tt.n[CHAIN_SPLIT];
             g.M = M; g.Xin = p.Xf; g.ldx = c->LDP; g.P = p.P; g.ldp = c->LDP; g.Z = p.Z0; g.ldz = KH; g.range_flag = c->d_range;
             launch_mlp_chain(g, CHAIN_SPLIT, s);
             break;
@@ -418,8 +459,8 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         if (c->fused && !force_f32()) {
             ChainLaunch g;
             memset(&g, 0, sizeof g);
-            g.desc = c->d_chain[CHAIN_MASK];
-            memcpy(g.n_cls, c->chain_ncls[CHAIN_MASK], sizeof g.n_cls);
+            const bsrnn_ctx::TaskTable& tt = c->chain_tasks.at(M);
+            g.desc = c->d_chain[CHAIN_MASK]; g.tasks = tt.d[CHAIN_MASK]; g.n_tasks = tt.n[CHAIN_MASK];
             g.M = M; g.Xin = p.Z0; g.ldx = KH; g.P = p.P; g.ldp = c->LDP; g.Xmul = p.Xf; g.ldm = c->LDP;
             g.Y = p.Yf; g.ldy = c->LDP; g.tap = p.tap; g.ldt = c->LDP; g.range_flag = c->d_range;
             launch_mlp_chain(g, CHAIN_MASK, s);
@@ -616,6 +657,8 @@ static void destroy_now(bsrnn_ctx* c)
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     for (int ch = 0; ch < 2; ++ch)
         if (c->d_chain[ch]) (void)hipFree(c->d_chain[ch]);
+    for (auto& kv : c->chain_tasks)
+        for (int ch = 0; ch < 2; ++ch) (void)hipFree(kv.second.d[ch]);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_colmap) (void)hipFree(c->d_colmap);
     if (c->h_range) (void)hipHostFree(c->h_range);
@@ -865,11 +908,10 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             const int cx = cls(x.d), cy = cls(y.d);
             return cx != cy ? cx < cy : x.cost > y.cost;
         });
-        memset(c->chain_ncls[ch], 0, sizeof c->chain_ncls[ch]);
+        c->chain_cost[ch].clear();
         for (const Built& bu : built) {
-            const int rows4 = 4 * bu.d.RT * (8 / bu.d.NW);        // rows per workgroup / 8: 32, 64 or 128 rows
-            ++c->chain_ncls[ch][bu.d.constant ? 3 : (rows4 == 4 ? 0 : (rows4 == 8 ? 1 : (rows4 == 16 ? 2 : 3)))];
             chains[ch].push_back(bu.d); ch_w[ch].push_back(bu.w); ch_b[ch].push_back(bu.b);
+            c->chain_cost[ch].push_back(bu.cost);
         }
     }
 
@@ -960,7 +1002,11 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     HIP_TRY(hipMalloc((void**)&c->d_tiles, tiles.size() * sizeof(int2)));
     HIP_TRY(hipMemcpy(c->d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
     c->fused = false;
+    for (auto& kv : c->chain_tasks)
+        for (int ch = 0; ch < 2; ++ch) (void)hipFree(kv.second.d[ch]);
+    c->chain_tasks.clear();
     for (int ch = 0; ch < 2; ++ch) {
+        c->h_chain[ch].clear();
         if (c->d_chain[ch]) { HIP_TRY(hipFree(c->d_chain[ch])); c->d_chain[ch] = nullptr; }
         if (!fused) continue;
         for (size_t i = 0; i < chains[ch].size(); ++i) {
@@ -969,6 +1015,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         }
         HIP_TRY(hipMalloc((void**)&c->d_chain[ch], chains[ch].size() * sizeof(ChainDesc)));
         HIP_TRY(hipMemcpy(c->d_chain[ch], chains[ch].data(), chains[ch].size() * sizeof(ChainDesc), hipMemcpyHostToDevice));
+        c->h_chain[ch] = chains[ch];
     }
     c->fused = fused;
     for (int blk = 0; blk < 2; ++blk) {
@@ -1056,7 +1103,7 @@ int bsrnn_forward(bsrnn_ctx* c, const float* x, float* y, float* mask, int32_t C
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
     const size_t M = (size_t)C * T;
-    if ((rc = ensure_ws(c, M))) return rc;
+    if ((rc = ensure_ws(c, M)) || (rc = ensure_tasks(c, (int)M))) return rc;
     if (mask && (rc = ensure_tap(c, M))) return rc;
     { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, T, s); }
     if ((rc = run_model(c, c->Xf, c->Yf, mask ? c->d_tap : nullptr, C, T, nullptr, nullptr, s))) return rc;
@@ -1078,7 +1125,7 @@ int bsrnn_forward_chunk(bsrnn_ctx* c, const float* x, const float* state_in, flo
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
     const size_t M = (size_t)C * L;
-    if ((rc = ensure_ws(c, M))) return rc;
+    if ((rc = ensure_ws(c, M)) || (rc = ensure_tasks(c, (int)M))) return rc;
     { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, L, s); }
     if ((rc = run_model(c, c->Xf, c->Yf, nullptr, C, L, state_in, state_out, s))) return rc;
     { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->tb, c->Yf, y, C, L, s); }
@@ -1177,6 +1224,7 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
     for (int j = 0; j < parts; ++j) {
         const int r0 = (int)((int64_t)R * j / parts), r1 = (int)((int64_t)R * (j + 1) / parts);
         pt[j] = make_part(c, r0, r1 - r0, T, parts > 1 ? c->aux[j] : s);
+        if ((rc = ensure_tasks(c, (r1 - r0) * T))) return rc;
         pt[j].wave = wave + (size_t)r0 * n; pt[j].n = n;
         pt[j].wave_out = wave_out + (size_t)r0 * out_len;
     }
@@ -1339,6 +1387,7 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     e = hipMemset(st->buf, 0, total * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(st->buf); delete st; return fail(BSRNN_EHIP, "hipMemset: %s", hipGetErrorString(e)); }
     rc = ensure_ws(c, C);
+    if (!rc) rc = ensure_tasks(c, C);
     if (rc) { (void)hipFree(st->buf); delete st; return rc; }
     ++c->live_streams;
     *out = st;
@@ -1394,7 +1443,7 @@ int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mi
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
-    if ((rc = ensure_ws(c, st->C))) return rc;
+    if ((rc = ensure_ws(c, st->C)) || (rc = ensure_tasks(c, st->C))) return rc;
     const size_t nb = (size_t)st->C * HOPS * sizeof(float);
     if (chunk != st->chunk) HIP_TRY(hipMemcpyAsync(st->chunk, chunk, nb, hipMemcpyDeviceToDevice, s));
     int mix_bits;

@@ -89,8 +89,9 @@ struct ChainDesc {
     int constant;        // zero-width band (TrainableConstantModule, bsrnn.py:12-24): Z[:, z_off .. +64) = bias[0 .. 64)
 };
 struct ChainLaunch {
-    const ChainDesc* desc;   // device array, grouped by class = rows per workgroup (32, 64, 128, 256; the constant bands are in
-    int n_cls[4];            //   the last), heaviest band first inside a class.  Blocks = sum n_cls[i] * ceil(M / rows_i).
+    const ChainDesc* desc;   // device array
+    const int2* tasks;       // device array [n_tasks]: (descriptor index, first frame row) of every workgroup, in dispatch order
+    int n_tasks;             //   (built per M by chain_tasks(): the fill-bound wide bands interleaved with the others)
     int M;
     const float* Xin; int ldx;       // SPLIT: spectrum rows; MASK: Z rows
     float* P; int ldp;               // SPLIT: written (bandFCs_pre output = the mask's residual); MASK: read
@@ -101,7 +102,8 @@ struct ChainLaunch {
     int* range_flag;
     unsigned long long* dbg;         // measurement only (CHAIN_TRACE builds of tools/chain_bench.hip): per-wave phase stamps
 };
-int chain_blocks(const ChainLaunch& g);
+// rows per workgroup of a descriptor (32 RT GR; 256 for a constant band)
+inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : 32 * d.RT * (8 / d.NW); }
 void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 
 // ------------------------------------------------------------------ dual-path LSTM kernels

@@ -29,7 +29,7 @@
 //   bands up to 768 columns: RT 1, GR 1 ( 32 rows, 96 KB image);   up to 544: RT 2, GR 1 ( 64 rows, shared weights);
 //   up to 288: RT 2, GR 2 (128 rows, two groups of 4 waves);        up to 192: RT 1, GR 4 (128 rows, four groups of 2 waves);
 //   up to 128: RT 1, GR 8 (256 rows: every wave runs the whole chain of its own row tile, no barriers).
-// One launch per chain; tasks (band, row block) in longest-first order.
+// One launch per chain over a task table (band, row block), longest workgroups first (api.hip, build_chain_tasks).
 #include "kernels.h"
 
 #include <type_traits>
@@ -378,19 +378,10 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
 {
     __shared__ __attribute__((aligned(16))) char smem[CHAIN_LDS_EX + CHAIN_LDS_BIAS];
 
-    // block -> (band, first row): classes of 32 / 64 / 128 / 256 rows per workgroup, class by class, band by band
-    int bid = blockIdx.x, di = 0, row0 = 0, cls = 0;
-    {
-        int rows = 32;
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl, rows *= 2) {
-            const int nblk = (g.M + rows - 1) / rows, ncl = g.n_cls[cl] * nblk;
-            if (bid < ncl || cl == 3) { di += bid / nblk; row0 = (bid - (bid / nblk) * nblk) * rows; cls = cl; break; }
-            bid -= ncl; di += g.n_cls[cl];
-        }
-    }
+    const int2 task = g.tasks[blockIdx.x];
+    const int di = task.x, row0 = task.y;
     const ChainDesc* const dp = g.desc + di;
-    if (cls == 3 && dp->constant) {
+    if (dp->constant) {
         // TrainableConstantModule (bsrnn.py:12-24): the zero-width band's feature is one learned vector for every frame
         if (CHAIN == CHAIN_SPLIT) {
             const gcf cst = (gcf)dp->bias;
@@ -410,18 +401,10 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
     else chain_body<CHAIN, TERMS, 1, 4>(g, dp, row0, smem);
 }
 
-int chain_blocks(const ChainLaunch& g)
-{
-    int n = 0, rows = 32;
-    for (int cl = 0; cl < 4; ++cl, rows *= 2) n += g.n_cls[cl] * ((g.M + rows - 1) / rows);
-    return n;
-}
-
 void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream)
 {
-    const int nblk = g.M > 0 ? chain_blocks(g) : 0;
-    if (nblk <= 0) return;
-    dim3 grid(nblk), block(512);
+    if (g.M <= 0 || g.n_tasks <= 0) return;
+    dim3 grid(g.n_tasks), block(512);
     const bool one = gemm_mode() == GEMM_FP16;
     if (chain == CHAIN_SPLIT) {
         if (one) hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_SPLIT, 1>), grid, block, 0, stream, g);

@@ -92,7 +92,6 @@ int main(int argc, char** argv)
         CK(hipMalloc(&dw, bu.w.size() * 2 + 64)); CK(hipMemcpy(dw, bu.w.data(), bu.w.size() * 2, hipMemcpyHostToDevice));
         CK(hipMalloc(&db, bu.b.size() * 4)); CK(hipMemcpy(db, bu.b.data(), bu.b.size() * 4, hipMemcpyHostToDevice));
         bu.d.wstream = dw; bu.d.bias = (const float*)db;
-        { const int r4 = 4 * bu.d.RT * (8 / bu.d.NW); ++g.n_cls[r4 == 4 ? 0 : (r4 == 8 ? 1 : (r4 == 16 ? 2 : 3))]; }
         descs.push_back(bu.d);
     }
     ChainDesc* dd;
@@ -107,6 +106,30 @@ int main(int argc, char** argv)
     CK(hipMalloc(&P, hx.size() * 4)); CK(hipMemcpy(P, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&Y, hx.size() * 4));
     CK(hipMalloc(&Z, hz.size() * 4)); CK(hipMemcpy(Z, hz.data(), hz.size() * 4, hipMemcpyHostToDevice));
+    // task table: heaviest band first, or (CHAIN_ORDER=mix) the 32-row workgroups interleaved with the others by work
+    std::vector<int2> tasks, wide, rest;
+    double ww = 0, wr = 0;
+    for (size_t di = 0; di < descs.size(); ++di)
+        for (int r0 = 0; r0 < M; r0 += chain_rows(descs[di])) {
+            const bool w = chain_rows(descs[di]) == 32;
+            (w ? wide : rest).push_back(make_int2((int)di, r0));
+            (w ? ww : wr) += (double)built[di].cost * descs[di].RT + 200.0;
+        }
+    if (getenv("CHAIN_ORDER") && !strcmp(getenv("CHAIN_ORDER"), "mix")) {
+        size_t i = 0, j = 0; double aw = 0, ar = 0;
+        while (i < wide.size() || j < rest.size()) {
+            const bool tw = j >= rest.size() || (i < wide.size() && aw * wr <= ar * ww);
+            const int2 t = tw ? wide[i++] : rest[j++];
+            (tw ? aw : ar) += (double)built[t.x].cost * descs[t.x].RT + 200.0;
+            tasks.push_back(t);
+        }
+    } else {
+        tasks = wide; tasks.insert(tasks.end(), rest.begin(), rest.end());
+    }
+    int2* dtasks;
+    CK(hipMalloc(&dtasks, tasks.size() * sizeof(int2)));
+    CK(hipMemcpy(dtasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice));
+    g.tasks = dtasks; g.n_tasks = (int)tasks.size();
     g.desc = dd; g.M = M;
     if (chain == 0) { g.Xin = X; g.ldx = LDP; g.P = P; g.ldp = LDP; g.Z = Z; g.ldz = KH; }
     else { g.Xin = Z; g.ldx = KH; g.P = P; g.ldp = LDP; g.Xmul = X; g.ldm = LDP; g.Y = Y; g.ldy = LDP; }
@@ -150,6 +173,6 @@ int main(int argc, char** argv)
         }
     }
     printf("chain %d  M %d  bands %s  PD %d ABL %d:  %d blocks  %.1f us  %.1f TFLOP/s-equivalent  weight stream %.2f GB -> %.2f TB/s\n", chain, M, sel.c_str(),
-           CHAIN_PD, CHAIN_ABL, chain_blocks(g), us, flop / us / 1e6, wbytes_per_tile * ((M + 31) / 32) / 1e9, wbytes_per_tile * ((M + 31) / 32) / us / 1e6);
+           CHAIN_PD, CHAIN_ABL, g.n_tasks, us, flop / us / 1e6, wbytes_per_tile * ((M + 31) / 32) / 1e9, wbytes_per_tile * ((M + 31) / 32) / us / 1e6);
     return 0;
 }
