@@ -85,6 +85,11 @@ int  bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx*
 void bsrnn_destroy(bsrnn_ctx* ctx);
 int  bsrnn_n_bands(const bsrnn_ctx* ctx);
 int  bsrnn_device(const bsrnn_ctx* ctx);
+/* 1 when the committed context runs the per-band MLP chains (bsrnn.py:404-415, :420-443) as fused launches (one workgroup =
+ * one band's five Linear layers, intermediates in LDS; the default), 0 when it runs one grouped launch per layer: the
+ * exact-fp32 mode, BSRNN_MLP=layers (A/B), or a band table with a band too wide for the fused kernel's LDS image
+ * (more than 768 columns).  Same arithmetic, bit-identical results either way. */
+int  bsrnn_mlp_fused(const bsrnn_ctx* ctx);
 
 /* ---- parameters ---------------------------------------------------------------------
  * Replaces `load_state_dict` (infer.py:19, infer-streaming.py:46): parameters are named

@@ -18,7 +18,7 @@ SYMBOLS = [
     "bsrnn_stft", "bsrnn_istft", "bsrnn_separate", "bsrnn_stream_create", "bsrnn_stream_destroy", "bsrnn_stream_reset",
     "bsrnn_stream_step", "bsrnn_stream_step_host", "bsrnn_stream_get_state", "bsrnn_set_profiling", "bsrnn_stage_count",
     "bsrnn_stage_name", "bsrnn_stage_times", "bsrnn_dev_alloc", "bsrnn_dev_free", "bsrnn_copy_h2d", "bsrnn_copy_d2h",
-    "bsrnn_sync", "bsrnn_evaluate", "bsrnn_io_count", "bsrnn_io_info",
+    "bsrnn_sync", "bsrnn_evaluate", "bsrnn_io_count", "bsrnn_io_info", "bsrnn_mlp_fused",
 ]
 METRIC_NAMES = ("loss", "sdr", "input_sdr", "sisdr", "l1_time", "l1_re", "l1_im", "separation_db")   # BSRNN_M_* order
 
@@ -47,6 +47,7 @@ def _load():
         "bsrnn_destroy": (None, [vp]),
         "bsrnn_n_bands": (C.c_int, [vp]),
         "bsrnn_device": (C.c_int, [vp]),
+        "bsrnn_mlp_fused": (C.c_int, [vp]),
         "bsrnn_param_count": (C.c_int, [vp]),
         "bsrnn_param_info": (C.c_int, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
         "bsrnn_set_param": (C.c_int, [vp, C.c_char_p, vp, i64]),

@@ -122,6 +122,11 @@ class BSRNN(nn.Module):
             self._pushed_fingerprint = fp
         return self._ctx
 
+    def mlp_flow(self, device=None):
+        """'fused' (one launch per MLP chain, the default) or 'layers' (one grouped launch per Linear layer) on `device`."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return "fused" if _lib.bsrnn_mlp_fused(self._context(dev)) == 1 else "layers"
+
     def refresh_weights(self):
         """Force re-upload (only needed after in-place edits that bypass tensor versioning)."""
         self._pushed_fingerprint = None

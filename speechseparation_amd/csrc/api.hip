@@ -675,6 +675,7 @@ void bsrnn_destroy(bsrnn_ctx* c)
 }
 
 int bsrnn_n_bands(const bsrnn_ctx* c) { return c ? c->K : -1; }
+int bsrnn_mlp_fused(const bsrnn_ctx* c) { return c ? (c->fused ? 1 : 0) : -1; }
 int bsrnn_device(const bsrnn_ctx* c) { return c ? c->device : -1; }
 int bsrnn_param_count(const bsrnn_ctx* c) { return c ? (int)c->params.size() : -1; }
 
@@ -881,7 +882,8 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             else if (4 * img <= CHAIN_LDS_EX && maxntl <= 12) { RT = 2; GR = 2; }    // two groups of four waves, two row tiles each
             else if (2 * img <= CHAIN_LDS_EX) { RT = 2; GR = 1; }
             else if (img <= CHAIN_LDS_EX) { RT = 1; GR = 1; }
-            if (RT < 1 || (8 / GR) * CHAIN_CT < maxntl || nbias * 4 > CHAIN_LDS_BIAS) { fused = false; break; }   // a band too wide for the fused kernel: per-layer flow
+            const int ct_max = GR == 8 ? 4 : CHAIN_CT;                                // feature tiles per wave the geometry's body holds
+            if (RT < 1 || (8 / GR) * ct_max < maxntl || nbias * 4 > CHAIN_LDS_BIAS) { fused = false; break; }   // a band too wide for the fused kernel: per-layer flow
             d.RT = RT; d.NW = 8 / GR; d.plane_units = units; d.nbias = nbias;
             d.in_off = ch == CHAIN_SPLIT ? c->poff[i] : i * H;
             d.K0 = ch == CHAIN_SPLIT ? round8(a) : H;

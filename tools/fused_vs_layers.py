@@ -17,6 +17,7 @@ x = m.stft(w[:3])
 f, mask = m.forward_with_mask(x)
 s = torch.zeros((4, 2, 3 * 12, 64), device='cuda')
 z, s = m.forward_chunk(x[:, :, :3].contiguous(), s)
+print("flow:", m.mlp_flow())
 np.savez(sys.argv[1], y=y, f=f.cpu().numpy(), mask=mask.cpu().numpy(), z=z.cpu().numpy(), s=s.cpu().numpy())
 '''
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,6 +32,7 @@ with tempfile.TemporaryDirectory() as d:
         r = subprocess.run([sys.executable, "-c", CODE, path, str(R), str(T)], env=env, cwd=repo, capture_output=True, text=True)
         if r.returncode:
             print(r.stdout[-2000:], r.stderr[-3000:]); sys.exit(1)
+        assert ("flow: " + flow) in r.stdout, r.stdout          # the child really ran the flow it was asked for
         outs[flow] = dict(np.load(path))
 for k in outs["fused"]:
     a, b = outs["fused"][k], outs["layers"][k]
