@@ -300,6 +300,25 @@ def separate(sd, wave, v=None, dtype=np.float32):
     return istft_interleaved(forward(sd, stft_interleaved(wave, dtype), v, dtype), dtype)
 
 
+def infer_outputs(sd, wave, v=None):
+    """The files infer.py writes for a [C, n] input (mono already duplicated, infer.py:26-27): the separated signal
+    (:29-42), the printed "Separation dB" (:44-47, natural log) and the five re-mixes mix_{100,90,50,20,-100}.wav
+    (:49-79): dialog + g * inst with inst = waveform - dialog, each scaled by orig_peak / mix.max() where orig_peak is
+    the input's largest (signed) sample (:28) and mix.max() the largest signed sample of the re-mix."""
+    wave = np.asarray(wave, np.float32)
+    orig_peak = wave.max()                                                   # :28
+    x = separate(sd, wave, v)                                                # :29-37
+    w = wave[:, :x.shape[1]]                                                 # :41
+    db = 10 * np.log(np.sum(np.square(w)) / np.sum(np.square(w - x)))        # :44-47
+    inst = w - x                                                             # :50
+    mixes = {}
+    for tag, g in (("100", 0.0), ("90", 0.3), ("50", 0.5), ("20", 0.8)):     # :51-73
+        mix = x + np.float32(g) * inst if g else x
+        mixes[tag] = mix * orig_peak / mix.max()
+    mixes["-100"] = inst * orig_peak / inst.max()                            # :75-79
+    return x, db, mixes
+
+
 # --------------------------------------------------------------------------- streaming (infer-streaming.py)
 class StreamingOracle:
     """infer-streaming.py:84-147.  Sliding 2048 buffer (zeros initially), one model step per
