@@ -882,8 +882,28 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             else if (4 * img <= CHAIN_LDS_EX && maxntl <= 12) { RT = 2; GR = 2; }    // two groups of four waves, two row tiles each
             else if (2 * img <= CHAIN_LDS_EX) { RT = 2; GR = 1; }
             else if (img <= CHAIN_LDS_EX) { RT = 1; GR = 1; }
+            // the widest bands (32 rows would be all the LDS holds): 48 rows on 16 x 16 x 32 MFMAs instead (chain_body48); there the
+            // layer fields count k-steps of 32 and feature tiles of 16
+            bool g48 = false;
+            if (RT == 1 && GR == 1 && !getenv("BSRNN_CHAIN_NO48")) {
+                int u48 = 0, maxft = 0, nb48 = 0;
+                for (int l = 0; l < CHAIN_LAYERS; ++l) {
+                    const int K32 = (ld[l].Kd + 31) / 32, FT = (ld[l].N + 15) / 16;
+                    u48 = imax(u48, 4 * K32);
+                    if (l + 1 < CHAIN_LAYERS) u48 = imax(u48, 2 * FT);
+                    maxft = imax(maxft, FT); nb48 += 16 * FT;
+                }
+                if (2 * u48 * 48 * 16 <= CHAIN_LDS_EX && maxft <= 8 * 6 && nb48 * 4 <= CHAIN_LDS_BIAS) {
+                    g48 = true; RT = 3; units = u48; nbias = 0; cost = 0;
+                    for (int l = 0; l < CHAIN_LAYERS; ++l) {
+                        d.L[l].K16 = (ld[l].Kd + 31) / 32; d.L[l].NTL = (ld[l].N + 15) / 16;
+                        d.L[l].bias_off = nbias; nbias += 16 * d.L[l].NTL;
+                        cost += (long)d.L[l].K16 * d.L[l].NTL;          // (half the MACs of a 32 x 32 x 16 unit each: same scale per row)
+                    }
+                }
+            }
             const int ct_max = GR == 8 ? 4 : CHAIN_CT;                                // feature tiles per wave the geometry's body holds
-            if (RT < 1 || (8 / GR) * ct_max < maxntl || nbias * 4 > CHAIN_LDS_BIAS) { fused = false; break; }   // a band too wide for the fused kernel: per-layer flow
+            if (!g48 && (RT < 1 || (8 / GR) * ct_max < maxntl || nbias * 4 > CHAIN_LDS_BIAS)) { fused = false; break; }   // a band too wide for the fused kernel: per-layer flow
             d.RT = RT; d.NW = 8 / GR; d.plane_units = units; d.nbias = nbias;
             d.in_off = ch == CHAIN_SPLIT ? c->poff[i] : i * H;
             d.K0 = ch == CHAIN_SPLIT ? round8(a) : H;
@@ -894,7 +914,8 @@ int bsrnn_commit_params(bsrnn_ctx* c)
                 const Param& w = P_(c, std::string(b) + ".weight");
                 const Param& bi = P_(c, std::string(b) + ".bias");
                 d.L[l].w_off = (unsigned)(stream.size() * sizeof(uint16_t));
-                pack_chain_layer_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, d.NW, gmode == GEMM_FP16 ? 1 : 2, stream);
+                if (g48) pack_chain_layer16_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, 8, gmode == GEMM_FP16 ? 1 : 2, stream);
+                else pack_chain_layer_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, d.NW, gmode == GEMM_FP16 ? 1 : 2, stream);
                 memcpy(&biases[d.L[l].bias_off], bi.data.data(), ld[l].N * sizeof(float));
             }
             stream.resize((stream.size() + 7) & ~size_t(7), 0);
@@ -906,7 +927,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         if (!fused) break;
         // class = rows per workgroup (RT = 1, 2, 4, constant bands), heaviest band first inside a class
         std::stable_sort(built.begin(), built.end(), [](const Built& x, const Built& y) {
-            auto cls = [](const ChainDesc& d) { const int rows = 4 * d.RT * (8 / d.NW); return d.constant ? 4 : (rows == 4 ? 0 : (rows == 8 ? 1 : (rows == 16 ? 2 : 3))); };
+            auto cls = [](const ChainDesc& d) { const int rows = chain_rows(d); return d.constant ? 4 : (rows <= 48 ? 0 : (rows == 64 ? 1 : (rows == 128 ? 2 : 3))); };
             const int cx = cls(x.d), cy = cls(y.d);
             return cx != cy ? cx < cy : x.cost > y.cost;
         });

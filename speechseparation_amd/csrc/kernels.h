@@ -79,7 +79,8 @@ struct ChainDesc {
     const void* wstream; // per layer, per wave wn: for tile t = wn + NW c, for ks, for piece: 64 lanes x 8 fp16 (split_host.h)
     const float* bias;   // the five bias vectors, each padded with zeros to NTL * 32 (constant band: the constant itself)
     int nbias;
-    int NW, RT;          // groups of NW waves share the feature tiles of their RT row tiles (of 32 rows): mlp_chain.hip
+    int NW, RT;          // groups of NW waves share the feature tiles of their RT row tiles (of 32 rows): mlp_chain.hip.
+                         // RT = 3: the 48-row geometry on 16 x 16 x 32 MFMAs (K16 then counts k-steps of 32, NTL tiles of 16)
     int plane_units;     // 512-byte units of one piece of one row tile's activation image: max(2 K16, 4 NTL) over the layers
     int in_off;          // first column of the band inside an input row (SPLIT: spectrum row, MASK: b * 64 of a Z row)
     int K0;              // valid input columns, a multiple of 8 (beyond: zeros)
@@ -103,7 +104,7 @@ struct ChainLaunch {
     unsigned long long* dbg;         // measurement only (CHAIN_TRACE builds of tools/chain_bench.hip): per-wave phase stamps
 };
 // rows per workgroup of a descriptor (32 RT GR; 256 for a constant band)
-inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : 32 * d.RT * (8 / d.NW); }
+inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : (d.RT == 3 ? 48 : 32 * d.RT * (8 / d.NW)); }
 void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 
 // ------------------------------------------------------------------ dual-path LSTM kernels

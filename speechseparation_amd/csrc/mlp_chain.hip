@@ -63,6 +63,9 @@ constexpr int PD = CHAIN_PD;
 #ifndef CHAIN_PRIO
 #define CHAIN_PRIO 0
 #endif
+#ifndef CHAIN_PD48
+#define CHAIN_PD48 4               // prefetch depth of the 48-row geometry (its k-steps carry two tiles' fragments)
+#endif
 
 __device__ __forceinline__ void split4(const v4f a, h4& p0, h4& p1)
 {
@@ -373,6 +376,249 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
     if (amax > 65504.f && g.range_flag) *g.range_flag = 1;
 }
 
+// The widest bands (more than 576 columns: the 768-wide band of the 12-band table) on v_mfma_f32_16x16x32_f16: 48 frame
+// rows per workgroup (three row tiles of 16) instead of 32 - all the 144 KB of LDS hold of a 768-column image.  These bands
+// are bound by the CU's fill rate from L2, every weight fragment is loaded once per workgroup, so rows per workgroup is what
+// counts: 1.5x the rows per weight byte, and 168 instead of 252 workgroups of that band (all resident at once on 256 CUs).
+//   A = weights:      lane (n = l & 15, kb = l >> 4) holds W[16 t + n][32 ks + 8 kb + j]     (feature tiles of 16)
+//   B = activations:  lane (m = l & 15, kb)          holds x[m][32 ks + 8 kb + j]: LDS image [k / 8][48 rows][8], per piece
+//   D: lane (m, g = l >> 4), register e: feature 16 t + 4 g + e of row m - four consecutive features, as in chain_body.
+// In this geometry ChainLayer::K16 counts k-steps of 32 and ChainLayer::NTL feature tiles of 16.
+template <int CHAIN, int TERMS>
+__device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDesc* const dp, const int row0, char* const smem)
+{
+    constexpr int NPL = TERMS == 1 ? 1 : 2;
+    constexpr int NW = 8, RT = 3, ROWS = 48, CTR = 6, UB = ROWS * 16;      // UB: bytes of one k-unit (8 k) of one piece
+    constexpr int PDR = CHAIN_PD48;               // k-steps in flight; a step is TWO feature tiles' fragments (4 KB per wave)
+    constexpr int TP = 2;                         // feature tiles per pass over K: each activation fragment read from LDS
+                                                  // feeds both (LDS read bandwidth is the co-bottleneck of 16 x 16 tiles)
+    float* const sbias = reinterpret_cast<float*>(smem + CHAIN_LDS_EX);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, gq = lane >> 4;
+    const int M = g.M;
+    int row[RT];
+    bool row_ok[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int rr = row0 + 16 * r + m;
+        row_ok[r] = rr < M;
+        row[r] = row_ok[r] ? rr : M - 1;
+    }
+    const int plane = dp->plane_units * UB;
+    float amax = 0.f;
+
+    constexpr int STEP = NPL * 1024;
+    const gcc wbase = (gcc)dp->wstream;
+    const unsigned lane16 = lane * 16;
+    h8 w[PDR][TP][NPL];
+    // k-step ks of the pass whose first tile's stream starts at p; `two`: the pass has a second tile (K32 steps further on)
+    auto wload = [&](int set, gcc p, int ks, int K32, bool two) {
+#pragma unroll
+        for (int tt = 0; tt < TP; ++tt) {
+            if (tt == 1 && !two) break;
+#pragma unroll
+            for (int pc = 0; pc < NPL; ++pc) w[set][tt][pc] = *(gch8)(p + (size_t)(tt * K32 + ks) * STEP + pc * 1024 + lane16);
+        }
+    };
+    auto layer_stream = [&](int l, int& K32, int& cnt, gcc& wp) {
+        K32 = dp->L[l].K16;
+        const int FT = dp->L[l].NTL;
+        const int full = FT / NW, rem = FT - full * NW;
+        cnt = full + (wn < rem ? 1 : 0);
+        const int before = wn * full + (wn < rem ? wn : rem);
+        wp = wbase + dp->L[l].w_off + (size_t)before * K32 * STEP;
+    };
+    auto prefetch_layer = [&](int l) {
+        int K32, cnt; gcc wp;
+        layer_stream(l, K32, cnt, wp);
+        if (cnt > 0) {
+#pragma unroll
+            for (int s = 0; s < PDR; ++s)
+                if (s < K32) wload(s, wp, s, K32, cnt > 1);
+        }
+    };
+    prefetch_layer(0);
+
+    // ---- biases -> LDS; the 48 input rows -> LDS, split on the way.  A wave instruction covers 16 rows x 2 k-units.
+    {
+        const gcf bsrc = (gcf)dp->bias;
+        const int nb = dp->nbias;
+        for (int i = tid; i < nb; i += 512) sbias[i] = bsrc[i];
+        const int U0 = 4 * dp->L[0].K16, K0 = dp->K0;             // k-units of the first layer's input
+        for (int u0 = 2 * wn; u0 < U0; u0 += 2 * NW * 2) {
+            v4f v[RT][2];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const gcf xin = (gcf)g.Xin + (size_t)row[r] * g.ldx + dp->in_off;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int k = 8 * (u0 + 2 * NW * i + (gq >> 1)) + 4 * (gq & 1);
+                    v[r][i] = (v4f){0.f, 0.f, 0.f, 0.f};
+                    if (k < K0) v[r][i] = *(gc4)(xin + k);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int u = u0 + 2 * NW * i + (gq >> 1);
+                    if (u >= U0) continue;
+                    const v4f x = v[r][i];
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+                    h4 p0, p1;
+                    split4(x, p0, p1);
+                    char* const d = smem + u * UB + (16 * r + m) * 16 + 8 * (gq & 1);
+                    *reinterpret_cast<h4*>(d) = p0;
+                    if (NPL == 2) *reinterpret_cast<h4*>(d + plane) = p1;
+                }
+        }
+    }
+    __syncthreads();
+
+    auto layer = [&](auto last_tag, const int l) {
+        constexpr bool last = decltype(last_tag)::value;
+        int K32, cnt; gcc wp;
+        layer_stream(l, K32, cnt, wp);
+        const int boff = dp->L[l].bias_off;
+        const bool leaky = dp->L[l].leaky != 0;
+        const bool to_p = CHAIN == CHAIN_SPLIT && l == 1;
+        h4 held[last ? 1 : CTR][RT][NPL];
+#pragma unroll
+        for (int c = 0; c < CTR; c += TP) {
+            if (c >= cnt) break;
+            const bool two = c + 1 < cnt;                         // wave-uniform: the pass has a second tile
+            const gcc tp = wp + (size_t)c * K32 * STEP;
+            const bool more = c + TP < cnt, more_two = c + TP + 1 < cnt;
+            v4f rv[TP][RT], mv[TP][RT];
+            if (CHAIN == CHAIN_MASK && last) {
+#pragma unroll
+                for (int tt = 0; tt < TP; ++tt) {
+                    const int n0 = 16 * (wn + NW * (c + tt)) + 4 * gq;
+                    const int nn = (n0 < dp->a8 && (tt == 0 || two)) ? n0 : 0;
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        rv[tt][r] = *(gc4)((gcf)g.P + (size_t)row[r] * g.ldp + dp->p_off + nn);
+                        mv[tt][r] = *(gc4)((gcf)g.Xmul + (size_t)row[r] * g.ldm + dp->p_off + nn);
+                    }
+                }
+            }
+            v4f hi[TP][RT], lo[TP][RT];
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) { hi[tt][r] = (v4f){0.f, 0.f, 0.f, 0.f}; lo[tt][r] = hi[tt][r]; }
+            h8 bn[RT][NPL];                                       // activation fragments, one k-step ahead of the MFMAs
+            auto bload = [&](int ks) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int pc = 0; pc < NPL; ++pc)
+                        bn[r][pc] = *reinterpret_cast<const h8*>(smem + pc * plane + (4 * ks + gq) * UB + (16 * r + m) * 16);
+            };
+            bload(0);
+            auto compute = [&](int set, int ks) {
+                h8 (&b)[RT][NPL] = bn;                            // (the next step's fragments are requested behind this step's MFMAs:
+                                                                  //  a second register set for them does not fit beside two tiles)
+                if (CHAIN_ABL & 1) {
+                    asm volatile("" ::"v"(w[set][0][0]), "v"(w[set][TP - 1][NPL - 1]), "v"(b[0][0]), "v"(b[RT - 1][NPL - 1]));
+                    if (!(CHAIN_ABL & 4)) bload(ks + 1 < K32 ? ks + 1 : ks);
+                    return;
+                }
+#pragma unroll
+                for (int tt = 0; tt < TP; ++tt) {
+                    if (tt == 1 && !two) break;
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        if (NPL == 2) {
+                            lo[tt][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[set][tt][0], b[r][NPL - 1], lo[tt][r], 0, 0, 0);      // w1 x2
+                            lo[tt][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[set][tt][NPL - 1], b[r][0], lo[tt][r], 0, 0, 0);      // w2 x1
+                        }
+                        hi[tt][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[set][tt][0], b[r][0], hi[tt][r], 0, 0, 0);                // w1 x1
+                    }
+                }
+                if (!(CHAIN_ABL & 4)) bload(ks + 1 < K32 ? ks + 1 : ks);
+            };
+            int ks0 = 0;
+            for (; ks0 + 2 * PDR <= K32; ks0 += PDR) {
+#pragma unroll
+                for (int s = 0; s < PDR; ++s) {
+                    compute(s, ks0 + s);
+                    if (!(CHAIN_ABL & 2)) wload(s, tp, ks0 + s + PDR, K32, two);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            for (; ks0 < K32; ks0 += PDR) {
+#pragma unroll
+                for (int s = 0; s < PDR; ++s) {
+                    const int ks = ks0 + s;
+                    if (ks < K32) {
+                        compute(s, ks);
+                        if (ks + PDR < K32) wload(s, tp, ks + PDR, K32, two);
+                        else if (more && s < K32) wload(s, tp + (size_t)TP * K32 * STEP, s, K32, more_two);      // the next pass
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            // ---- the tiles' epilogue
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt) {
+            if (tt == 1 && !two) break;
+            const int n0 = 16 * (wn + NW * (c + tt)) + 4 * gq;    // first of this lane's 4 consecutive features
+            const v4f bv = *reinterpret_cast<const v4f*>(&sbias[boff + n0]);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                v4f v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sum = TERMS == 1 ? hi[tt][r][e] : hi[tt][r][e] + (1.f / 2048.f) * lo[tt][r][e];
+                    v[e] = sum + bv[e];
+                    if (leaky) v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                }
+                if (!last) {
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+                    h4 p0, p1;
+                    split4(v, p0, p1);
+                    held[last ? 0 : c + tt][r][0] = p0;
+                    held[last ? 0 : c + tt][r][NPL - 1] = NPL == 2 ? p1 : p0;
+                    if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0) = v;
+                } else if (CHAIN == CHAIN_SPLIT) {
+                    if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)row[r] * g.ldz + dp->z_off + n0) = v;
+                } else {
+                    if (row_ok[r] && n0 < dp->a8) {
+                        v += rv[tt][r];                                              // mask = residual + post(...)   bsrnn.py:425
+                        if (g.tap) *(g4)((gf)g.tap + (size_t)row[r] * g.ldt + dp->p_off + n0) = v;
+                        *(g4)((gf)g.Y + (size_t)row[r] * g.ldy + dp->p_off + n0) = v * mv[tt][r];   // x * mask   bsrnn.py:441
+                    }
+                }
+            }
+            }
+        }
+        if (last) return;
+        prefetch_layer(l + 1);                                   // in flight across the barriers
+        __syncthreads();                                         // every wave has read the layer's input image
+#pragma unroll
+        for (int c = 0; c < CTR; ++c) {
+            if (c >= cnt) break;
+            const int t = wn + NW * c;
+            // features 16 t + 4 gq .. + 3: k-unit 2 t + (gq >> 1), half (gq & 1)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                char* const d = smem + (2 * t + (gq >> 1)) * UB + (16 * r + m) * 16 + 8 * (gq & 1);
+                *reinterpret_cast<h4*>(d) = held[last ? 0 : c][r][0];
+                if (NPL == 2) *reinterpret_cast<h4*>(d + plane) = held[last ? 0 : c][r][NPL - 1];
+            }
+        }
+        __syncthreads();                                         // the next layer's input image is complete
+    };
+#pragma unroll 1
+    for (int l = 0; l < CHAIN_LAYERS - 1; ++l) layer(std::false_type(), l);
+    layer(std::true_type(), CHAIN_LAYERS - 1);
+    if (amax > 65504.f && g.range_flag) *g.range_flag = 1;
+}
+
 template <int CHAIN, int TERMS>
 __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
 {
@@ -392,9 +638,10 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
         }
         return;
     }
-    // geometry of the workgroup (wave-uniform): rows = 32 RT GR
+    // geometry of the workgroup (wave-uniform): 48 rows on 16 x 16 tiles, or rows = 32 RT GR on 32 x 32 tiles
     const int RT = dp->RT, GR = 8 / dp->NW;
-    if (GR == 8) chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem);
+    if (RT == 3) chain_body48<CHAIN, TERMS>(g, dp, row0, smem);
+    else if (GR == 8) chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem);
     else if (RT == 1 && GR == 1) chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem);
     else if (RT == 2 && GR == 1) chain_body<CHAIN, TERMS, 2, 1>(g, dp, row0, smem);
     else if (RT == 2 && GR == 2) chain_body<CHAIN, TERMS, 2, 2>(g, dp, row0, smem);

@@ -98,6 +98,25 @@ inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW,
                         }
 }
 
+// The same for the 48-row geometry on v_mfma_f32_16x16x32_f16 (feature tiles of 16, k-steps of 32): lane (n = l & 15,
+// kb = l >> 4) holds W[16 t + n][32 ks + 8 kb + j].
+inline void pack_chain_layer16_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out)
+{
+    const int K32 = (K + 31) / 32, FT = (N + 15) / 16;
+    for (int wn = 0; wn < NW; ++wn)
+        for (int t = wn; t < FT; t += NW)
+            for (int ks = 0; ks < K32; ++ks)
+                for (int pc = 0; pc < npl; ++pc)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = 16 * t + (l & 15), k = 32 * ks + 8 * (l >> 4) + j;
+                            const float v = (n < N && k < K) ? w[(size_t)n * ldw + k] : 0.f;
+                            uint16_t p[2];
+                            split_planes_host(&v, 1, 2, p);
+                            out.push_back(p[pc]);
+                        }
+}
+
 inline float join_planes_host(const uint16_t* planes, size_t n, size_t i, int np)
 {
     if (np == 3) return (bf16_to_float(planes[i]) + bf16_to_float(planes[n + i])) + bf16_to_float(planes[2 * n + i]);

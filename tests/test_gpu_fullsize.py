@@ -89,17 +89,32 @@ def run_child(kind, env_extra, d, tag):
     return r.stdout, dict(np.load(path))
 
 
-@pytest.mark.parametrize("kind", ["b12", "b41"])
-def test_fused_chains_equal_the_per_layer_flow_bit_for_bit(kind):
+@pytest.mark.parametrize("kind,no48", [("b12", True), ("b41", False)])
+def test_fused_chains_equal_the_per_layer_flow_bit_for_bit(kind, no48):
     """The fused chain kernel (mlp_chain.hip, the default) multiplies the same fp16 pieces in the same k order as the
-    per-layer launches (BSRNN_MLP=layers): separate(), forward (output and mask) and a chunk with state must be EQUAL, for
-    the 12-band table (geometries 32 / 64 / 128 / 256 rows per workgroup, ragged row counts) and the 41-band table."""
+    per-layer launches (BSRNN_MLP=layers) wherever it uses the same 32 x 32 x 16 MFMA: separate(), forward (output and
+    mask) and a chunk with state must be EQUAL, for the 12-band table (geometries of 32 / 64 / 128 / 256 rows per
+    workgroup, ragged row counts; BSRNN_CHAIN_NO48 keeps its 768-wide band on the 32 x 32 geometry) and the 41-band table."""
+    extra = {"BSRNN_CHAIN_NO48": "1"} if no48 else {}
     with tempfile.TemporaryDirectory() as d:
-        out_f, fused = run_child(kind, {}, d, "fused")
-        out_l, layers = run_child(kind, {"BSRNN_MLP": "layers"}, d, "layers")
+        out_f, fused = run_child(kind, extra, d, "fused")
+        out_l, layers = run_child(kind, dict(extra, BSRNN_MLP="layers"), d, "layers")
     assert "flow: fused" in out_f and "flow: layers" in out_l
     for k in fused:
         assert np.array_equal(fused[k], layers[k]), k
+
+
+def test_48_row_geometry_of_the_widest_band_is_at_rounding_level():
+    """By default the 768-wide band runs 48 rows per workgroup on v_mfma_f32_16x16x32_f16: the same products, summed 32
+    instead of 16 per instruction, so not bit-identical to the 32 x 32 x 16 kernels - but at fp32 rounding level."""
+    with tempfile.TemporaryDirectory() as d:
+        out_f, fused = run_child("b12", {}, d, "fused")
+        out_l, layers = run_child("b12", {"BSRNN_MLP": "layers"}, d, "layers")
+    assert "flow: fused" in out_f and "flow: layers" in out_l
+    for k in fused:
+        rel = maxabs(fused[k], layers[k]) / np.abs(layers[k]).max()
+        print("%s: 48-row geometry vs per-layer flow, relative to the range %.2e" % (k, rel))
+        assert rel < 1e-6, (k, rel)
 
 
 def test_config2_16bit_gemm_mode_full_size():

@@ -64,6 +64,16 @@ int main(int argc, char** argv)
         else if (4 * img <= CHAIN_LDS_EX && maxntl <= 12) { RT = 2; GR = 2; }
         else if (2 * img <= CHAIN_LDS_EX) { RT = 2; GR = 1; }
         if (getenv("CHAIN_GEOM")) sscanf(getenv("CHAIN_GEOM"), "%d,%d", &RT, &GR);      // override (must fit the LDS)
+        const bool g48 = RT == 1 && GR == 1 && !getenv("BSRNN_CHAIN_NO48");
+        if (g48) {
+            RT = 3; units = 0; nbias = 0;
+            for (int l = 0; l < 5; ++l) {
+                const int N = chain ? dims_m[l][0] : dims_s[l][0], Kd = chain ? dims_m[l][1] : dims_s[l][1];
+                d.L[l].K16 = (Kd + 31) / 32; d.L[l].NTL = (N + 15) / 16; d.L[l].bias_off = nbias; nbias += 16 * d.L[l].NTL;
+                units = std::max(units, 4 * d.L[l].K16);
+                if (l < 4) units = std::max(units, 2 * d.L[l].NTL);
+            }
+        }
         d.RT = RT; d.NW = 8 / GR; d.plane_units = units; d.nbias = nbias;
         d.in_off = chain ? i * H : poff[i]; d.K0 = chain ? H : d.a8;
         bu.b.assign(nbias, 0.f);
@@ -72,15 +82,16 @@ int main(int argc, char** argv)
             std::vector<float> w((size_t)N * Kd);
             for (auto& x : w) x = frand(seed) / sqrtf((float)Kd);
             d.L[l].w_off = (unsigned)(bu.w.size() * 2);
-            pack_chain_layer_host(w.data(), N, Kd, Kd, d.NW, 2, bu.w);
+            if (g48) pack_chain_layer16_host(w.data(), N, Kd, Kd, 8, 2, bu.w);
+            else pack_chain_layer_host(w.data(), N, Kd, Kd, d.NW, 2, bu.w);
             for (int n = 0; n < N; ++n) bu.b[d.L[l].bias_off + n] = 0.1f * frand(seed);
         }
-        wbytes_per_tile += bu.w.size() * 2 / d.RT;      // per 32 rows: a wave group streams the weights once for its RT row tiles
+        wbytes_per_tile += g48 ? bu.w.size() * 2 * 32 / 48 : bu.w.size() * 2 / d.RT;      // per 32 rows: a wave group streams the weights once for its rows
         printf("band %2d a=%4d  NW=%d RT=%d  units=%3d  weights %.2f MB  cost %ld\n", i, a, d.NW, d.RT, units, bu.w.size() * 2 / 1e6, bu.cost);
         built.push_back(std::move(bu));
     }
     std::stable_sort(built.begin(), built.end(), [](const Built& x, const Built& y) {
-        auto cls = [](const ChainDesc& d) { const int r4 = 4 * d.RT * (8 / d.NW); return r4 == 4 ? 0 : (r4 == 8 ? 1 : (r4 == 16 ? 2 : 3)); };
+        auto cls = [](const ChainDesc& d) { const int r = chain_rows(d); return r <= 48 ? 0 : (r == 64 ? 1 : (r == 128 ? 2 : 3)); };
         const int cx = cls(x.d), cy = cls(y.d);
         return cx != cy ? cx < cy : x.cost > y.cost;
     });
@@ -111,7 +122,7 @@ int main(int argc, char** argv)
     double ww = 0, wr = 0;
     for (size_t di = 0; di < descs.size(); ++di)
         for (int r0 = 0; r0 < M; r0 += chain_rows(descs[di])) {
-            const bool w = chain_rows(descs[di]) == 32;
+            const bool w = chain_rows(descs[di]) <= 48;
             (w ? wide : rest).push_back(make_int2((int)di, r0));
             (w ? ww : wr) += (double)built[di].cost * descs[di].RT + 200.0;
         }
