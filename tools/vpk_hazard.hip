@@ -57,6 +57,47 @@ __global__ __launch_bounds__(256) void victim(unsigned long long* bad, int iters
     if (mism) atomicAdd(bad, mism);
 }
 
+// Hypothesis H2 (round 2): in the vectorised FFT passes an LDS store is followed IMMEDIATELY by a packed-fp32 instruction
+// that overwrites part of the store's data registers (a write-after-read on registers the LDS unit is still fetching):
+//     ds_write_b128 v104, v[110:113]            ds_write2st64_b64 v18, v[92:93], v[94:95] offset1:4
+//     v_pk_add_f32  v[112:113], ...             v_pk_mul_f32      v[92:93], ...
+// The scalar build has the same adjacency with v_sub / v_mul (47 places) and is clean, so the hardware interlocks scalar
+// VALU writes against an LDS store's pending data fetch; is a packed write interlocked as well when another kernel's MFMAs
+// compete for the VGPR read ports?  The victim stores a known 16-byte value, overwrites half of its registers with poison
+// by the very next instruction (MODE 0 / 2: v_pk_add_f32, MODE 1 / 3: two scalar v_add_f32 - the control), and reads the
+// LDS back: poison in LDS = the store fetched its data after the overwrite.
+template <int MODE>
+__global__ __launch_bounds__(256) void victim_war(unsigned long long* bad, int iters)
+{
+    __shared__ __attribute__((aligned(16))) float buf[2][256 * 4 + 16 * 256];
+    const int tid = threadIdx.x;
+    unsigned long long mism = 0;
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    for (int it = 0; it < iters; ++it) {
+        const float base = (float)(it & 1023) + 0.001f * tid;
+        v4f_ d = {base, base + 1.f, base + 2.f, base + 3.f};
+        const v2f px = {1e30f, 1e30f}, py = {1e30f, 1e30f};
+        float* slot = &buf[it & 1][MODE < 2 ? 4 * tid : 2 * tid];      // (st64 form: second 8 bytes land 2048 bytes further)
+        const unsigned addr = (unsigned)(size_t)slot;              // LDS byte address (the low 32 bits of the generic pointer)
+        if (MODE == 0)
+            asm volatile("ds_write_b128 %1, v[20:23]\n\tv_pk_add_f32 v[22:23], %2, %3" : "+{v[20:23]}"(d) : "v"(addr), "v"(px), "v"(py) : "memory");
+        else if (MODE == 1)
+            asm volatile("ds_write_b128 %1, v[20:23]\n\tv_add_f32 v22, %2, %3\n\tv_add_f32 v23, %2, %3" : "+{v[20:23]}"(d) : "v"(addr), "v"(px.x), "v"(py.x) : "memory");
+        else if (MODE == 2)
+            asm volatile("ds_write2st64_b64 %1, v[20:21], v[22:23] offset1:4\n\tv_pk_mul_f32 v[20:21], %2, %3" : "+{v[20:23]}"(d) : "v"(addr), "v"(px), "v"(py) : "memory");
+        else
+            asm volatile("ds_write2st64_b64 %1, v[20:21], v[22:23] offset1:4\n\tv_mul_f32 v20, %2, %3\n\tv_mul_f32 v21, %2, %3" : "+{v[20:23]}"(d) : "v"(addr), "v"(px.x), "v"(py.x) : "memory");
+        __syncthreads();
+        float got[4];
+        if (MODE < 2) { for (int e = 0; e < 4; ++e) got[e] = slot[e]; }
+        else { got[0] = slot[0]; got[1] = slot[1]; got[2] = slot[512]; got[3] = slot[513]; }    // offset1:4 = 4 * 64 * 8 bytes = 512 floats further
+        for (int e = 0; e < 4; ++e) mism += got[e] != base + (float)e;
+        asm volatile("" :: "v"(d));
+        __syncthreads();
+    }
+    if (mism) atomicAdd(bad, mism);
+}
+
 __global__ __launch_bounds__(256) void aggressor(float* sink, int iters)
 {
     h8 x, y;
@@ -93,6 +134,28 @@ int main()
             }
             printf("victim %s LDS exchange, %s: %llu packed results differ from their scalar twins (20 launches x 2048 x 256 lanes x 20000 x 12)\n",
                    use_lds ? "with" : "without", with_aggr ? "beside an MFMA kernel" : "alone", total);
+        }
+    // H2: write-after-read between an LDS store's data registers and the next (packed / scalar) instruction
+    const char* names[4] = {"ds_write_b128 + v_pk_add_f32", "ds_write_b128 + 2 x v_add_f32 (control)", "ds_write2st64_b64 + v_pk_mul_f32",
+                            "ds_write2st64_b64 + 2 x v_mul_f32 (control)"};
+    for (int mode = 0; mode < 4; ++mode)
+        for (int with_aggr = 0; with_aggr < 2; ++with_aggr) {
+            unsigned long long total = 0;
+            for (int rep = 0; rep < 10; ++rep) {
+                CK(hipMemsetAsync(d_bad, 0, 8, sb));
+                CK(hipStreamSynchronize(sb));
+                if (with_aggr) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), 0, sa, d_sink, 40000);
+                if (mode == 0) hipLaunchKernelGGL(victim_war<0>, dim3(2048), dim3(256), 0, sb, d_bad, 4000);
+                else if (mode == 1) hipLaunchKernelGGL(victim_war<1>, dim3(2048), dim3(256), 0, sb, d_bad, 4000);
+                else if (mode == 2) hipLaunchKernelGGL(victim_war<2>, dim3(2048), dim3(256), 0, sb, d_bad, 4000);
+                else hipLaunchKernelGGL(victim_war<3>, dim3(2048), dim3(256), 0, sb, d_bad, 4000);
+                CK(hipStreamSynchronize(sb)); CK(hipStreamSynchronize(sa));
+                unsigned long long h = 0;
+                CK(hipMemcpy(&h, d_bad, 8, hipMemcpyDeviceToHost));
+                total += h;
+            }
+            printf("H2 %-46s %-22s: %llu of %.3g stored words read back wrong\n", names[mode], with_aggr ? "beside an MFMA kernel" : "alone", total,
+                   10.0 * 2048 * 256 * 4000 * 4);
         }
     return 0;
 }
