@@ -85,6 +85,7 @@ struct bsrnn_ctx {
     int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT], tile_n[NSLOT];
 
     // fused per-band MLP chains (mlp_chain.hip): device descriptor arrays, grouped by class (kernels.h, ChainLaunch)
+    bool small_rows = false;        // the call in flight has <= GEMV_MAX_FRAME_ROWS frame rows: per-layer GEMV launches (gemv.hip)
     bool fused = false;             // false: per-layer launches (BSRNN_MLP=layers, fp32 mode, or a band too wide for the LDS image)
     ChainDesc* d_chain[2] = {nullptr, nullptr};
     std::vector<ChainDesc> h_chain[2];          // host copies (geometry and cost per band: the task tables are made from them)
@@ -369,7 +370,10 @@ void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ld
     g.tile_n = c->tile_n[slot];
     g.X = X; g.ldx = ldx; g.Y = Y; g.ldy = ldy; g.R = R; g.ldr = ldr; g.Mul = Mul; g.ldm = ldm;
     g.tap = tap; g.ldt = c->LDP; g.M = M; g.epilogue = epi;
-    launch_gemm(g, s);
+    // a call of a few frame rows: its per-band layers (M = C rows) run as exact-fp32 GEMV launches instead of 128-row MFMA
+    // tiles; the block fc layers (M K rows against a 64 x 128 matrix) stay on the MFMA kernel (measured: 5.7 vs 28 us)
+    if (c->small_rows && M <= 2 * GEMV_MAX_FRAME_ROWS) launch_gemv(g, s);
+    else launch_gemm(g, s);
 }
 
 // A contiguous block of rows (utterance-channels) of one call, with its slice of the workspace
@@ -411,7 +415,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         break;
     case MS_BANDSPLIT: {   // bandFCs_pre (2 linears) -> residual P; bandFCs (3 linears) -> Z0   bsrnn.py:404-415
         StageScope sc(c, ST_BANDSPLIT, s);
-        if (c->fused && !force_f32()) {      // all five layers of every band in one launch, intermediates in LDS
+        if (c->fused && !force_f32() && !c->small_rows) {      // all five layers of every band in one launch, intermediates in LDS
             ChainLaunch g;
             memset(&g, 0, sizeof g);
             const bsrnn_ctx::TaskTable& tt = c->chain_tasks.at(M);       // made by ensure_chain_tasks() before any launch (and outside graph capture)
@@ -456,7 +460,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     }
     case MS_MASK: {   // bandFCs_back (3) + bandFCs_back_post (2) + skip + x*mask   bsrnn.py:420-443
         StageScope sc(c, ST_MASK, s);
-        if (c->fused && !force_f32()) {
+        if (c->fused && !force_f32() && !c->small_rows) {
             ChainLaunch g;
             memset(&g, 0, sizeof g);
             const bsrnn_ctx::TaskTable& tt = c->chain_tasks.at(M);
@@ -486,11 +490,14 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
 int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T,
               const float* state_in, float* state_out, hipStream_t s)
 {
+    static const bool gemv_on = [] { const char* e = getenv("BSRNN_GEMV"); return !(e && !strcmp(e, "0")); }();
+    c->small_rows = gemv_on && C * T <= GEMV_MAX_FRAME_ROWS;
     Part p = make_part(c, 0, C, T, s);
     p.Xf = Xf; p.Yf = Yf; p.tap = tap;
     p.state_in = state_in; p.state_out = state_out;
     p.state_slab = (size_t)2 * 2 * C * c->K * HID;     // one Time block's (h,c) x 2 layers
     for (int st = MS_BANDSPLIT; st <= MS_MASK; ++st) run_stage(c, p, st);
+    c->small_rows = false;
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -49,6 +49,10 @@ struct GemmLaunch {
     int* range_flag;                   // fp16x2: set to 1 when an operand exceeded the fp16 range (may be null)
 };
 void launch_gemm(const GemmLaunch& g, hipStream_t stream);
+// Small-M path (gemv.hip): the same launch on the vector ALU in exact fp32, for calls of a few frame rows (the one-frame
+// streaming step: C rows).  api.hip uses it for every per-layer launch of a call with C * L <= GEMV_MAX_FRAME_ROWS.
+constexpr int GEMV_MAX_FRAME_ROWS = 4;
+void launch_gemv(const GemmLaunch& g, hipStream_t stream);
 // How the Linear layers are evaluated (environment BSRNN_GEMM = f32 | fp16x2 | fp16, read once per process).
 // fp16 = plain 16-bit operands, one MFMA term, fp32 accumulate (the reduced-precision configuration, not the default).
 // The fp32 weights are always resident beside the fp16 pieces: a call whose operands left the fp16x2 range is re-run on
