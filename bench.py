@@ -358,7 +358,11 @@ def main():
         from speechseparation_amd import _native
         cmode = _native.compute_mode()
         flow = mlp_flow(cmode["gemm"])
-        n_launch = 2 if flow == "fused" else 10
+        # launches of the dominant family per step: every bracket of the two MLP stages holds 1 (fused) or 5 (per-layer)
+        # launches, and bsrnn_separate runs the batch as `blocks` concurrent row blocks (2 from 64 rows on), each with its own
+        n_brackets = sum(dom_stages[k][1] for k in DOMINANT) / float(args.steps)
+        blocks = max(1, int(round(n_brackets / 2.0)))
+        n_launch = int(round(n_brackets)) * (1 if flow == "fused" else 5)
         kname, peak, basis = GEMM_ROOF[cmode["gemm"]]
         if flow == "fused":
             kname = "mlp_chain_kernel"
@@ -366,10 +370,11 @@ def main():
         achieved = dom_flop_step / (dom_ms_step * 1e-3) / 1e12
         act_bytes = gemm_activation_bytes(spec.generate_bandsplits()[0], flow)
         roofline = {"kernel": "%s (the per-band MLP chains BandSplit + MaskEstimation, %s: %d launches/step)" % (
-                        kname, "fused, intermediates in LDS" if flow == "fused" else "one grouped launch per layer", n_launch),
+                        kname, "fused, intermediates in LDS" if flow == "fused" else "one grouped launch per layer", n_launch) +
+                              (" over %d concurrent row blocks of %d rows" % (blocks, (hi - lo) // blocks) if blocks > 1 else ""),
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms_step / n_launch, 4), "launches_per_step": n_launch,
+                    "row_blocks": blocks, "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms_step / n_launch, 4), "launches_per_step": n_launch,
                     "flop_per_launch_avg": dom_flop_step / n_launch, "peak_basis": basis,
                     "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "hbm_view": {"algorithmic_bytes_per_launch_avg": act_bytes * rf / n_launch,

@@ -116,12 +116,14 @@ struct bsrnn_ctx {
     hipStream_t last_stream = nullptr;
 
     // concurrent row blocks of one call (bsrnn_separate)
-    // BSRNN_PARTS / BSRNN_PART_LAG.  0 = automatic: one block below 128 rows (at R = 64 two half-size blocks gain 2 %, but
-    // the stage brackets and kernel durations of concurrent blocks overlap, which blurs the per-kernel accounting), two
-    // blocks of >= 64 rows from 128 rows on: each block keeps full-size launches and the other block's matrix work fills
-    // the latency-bound time-axis LSTM (+8-12 % at 128 rows).  Rows are independent; tests/test_gpu_edges.py checks a
-    // 130-row call bit for bit against its row blocks.  (That check first failed: see the note at the top of fft.hip.)
-    int n_parts = 0, part_lag = 0;
+    // BSRNN_PARTS / BSRNN_PART_LAG.  0 = automatic: two row blocks on two streams from 128 rows on (blocks of >= 64 rows), the
+    // second one stage behind the first: one block's matrix work fills the other's latency-bound time-axis LSTM (192 of 256
+    // CUs, serial chain) and the ramps / tails of the fused chain launches (+8-12 % at 128 rows).  At the benchmark's 64 rows
+    // two blocks of 32 gain 3 % (1.157 -> 1.119 ms per step, BSRNN_PARTS=2) but every kernel then runs beside another
+    // block's kernels: the per-kernel durations (and with them the roofline figure of bench.py) stop describing the kernel,
+    // so one block there.  Rows are independent; tests/test_gpu_edges.py checks 64- and 130-row calls bit for bit against
+    // their row blocks.  (That check first failed: see the note at the top of fft.hip.)
+    int n_parts = 0, part_lag = 1;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
 };

@@ -140,23 +140,26 @@ def test_frame_counts_around_the_kernels_chunk_sizes(sd_default, T):
     assert maxabs(torch.cat([y1, y2], dim=2).cpu().numpy(), y_off.cpu().numpy()) < 2e-5
 
 
-def test_large_batches_equal_their_row_blocks(sd_default):
+@pytest.mark.parametrize("rows", [64, 130])
+def test_large_batches_equal_their_row_blocks(sd_default, rows):
     """Rows are independent (bsrnn.py:394-395).  From 128 rows on bsrnn_separate runs two row blocks concurrently on two
-    streams: a 130-row call must equal the same rows separated block by block, bit for bit, run to run, and the oracle on
-    a few rows.  (This check exposed the co-residency hazard of the vectorised FFT kernels, csrc/fft.hip.)"""
+    streams (the second a stage behind): a 130-row call - and a 64-row one, the benchmark's shape - must equal the same
+    rows separated block by block, bit for bit, run to run, and the oracle on a few rows.  (This check exposed the co-residency
+    hazard of the vectorised FFT kernels, csrc/fft.hip.)"""
     from oracle import bsrnn_numpy as onp
     from speechseparation_amd import weights
     m = make_model(sd_default)
-    wave = weights.synth_waveform(130, 16 * 1024 + 9, seed=31)
+    wave = weights.synth_waveform(rows, 16 * 1024 + 9, seed=31)
     w = torch.from_numpy(wave).cuda()
     whole = m.separate(w).cpu().numpy()
-    halves = np.concatenate([m.separate(w[:65].contiguous()).cpu().numpy(), m.separate(w[65:].contiguous()).cpu().numpy()], 0)
+    h = rows // 2
+    halves = np.concatenate([m.separate(w[:h].contiguous()).cpu().numpy(), m.separate(w[h:].contiguous()).cpu().numpy()], 0)
     assert np.array_equal(whole, halves)
     for _ in range(5):
         assert np.array_equal(whole, m.separate(w).cpu().numpy())
-    rows = [0, 64, 65, 129]
-    ref = onp.separate(sd_default, wave[rows])
-    assert maxabs(whole[rows], ref) < TOL
+    pick = [0, h - 1, h, rows - 1]
+    ref = onp.separate(sd_default, wave[pick])
+    assert maxabs(whole[pick], ref) < TOL
 
 
 def test_stream_survives_regrow_and_recommit(sd_default, sd_hot):
