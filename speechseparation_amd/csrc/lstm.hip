@@ -16,6 +16,13 @@
 #include <cstdlib>
 #include <cstring>
 
+#ifndef BAND_NLDS
+#define BAND_NLDS 3
+#endif
+#ifndef BAND_ABL
+#define BAND_ABL 0                // measurement only (tools/lstm_h2_trace.hip): bit 1 no x staging, 2 no global h store, 4 no h publish, 8 no step barrier, 16 no MFMAs, 32 no transcendentals
+#endif
+
 namespace bsrnn {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -31,10 +38,12 @@ __device__ __forceinline__ float fast_tanh(float x)
 }
 __device__ __forceinline__ v4f exp2_4(const v4f x)
 {
+    if (BAND_ABL & 32) return x * 0.5f;
     return (v4f){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1]), __builtin_amdgcn_exp2f(x[2]), __builtin_amdgcn_exp2f(x[3])};
 }
 __device__ __forceinline__ v4f rcp4(const v4f x)
 {
+    if (BAND_ABL & 32) return x * 0.25f;
     return (v4f){__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1]), __builtin_amdgcn_rcpf(x[2]), __builtin_amdgcn_rcpf(x[3])};
 }
 
@@ -182,6 +191,7 @@ __global__ __launch_bounds__(256, BAND_OCC) void band_lstm_kernel(const float* _
 // =====================================================================================
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_h2(const float v, _Float16& p0, _Float16& p1)
 {
@@ -199,14 +209,17 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
     if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
     constexpr int NBX = IN / 32, NBH = HID / 32, NB = NBX + NBH;
+    constexpr bool PLANES_IN = IN == 2 * HID;    // layer 1: x arrives as the fp16 planes layer 0 wrote
+    constexpr bool PLANES_OUT = IN == HID;       // layer 0: h leaves as fp16 planes (read by layer 1 only)
     // blocks whose second weight piece lives in LDS instead of VGPRs (counted from the last k block): the 128-input
     // layer would need 192 weight + 32 accumulator registers; with 3 blocks (both of W_hh, the last of W_ih) in LDS
     // it is 144 + 32 and compiles without scratch (measured with spills: 1.9 us of every 3.5 us step in reloads)
-    constexpr int NLDS = IN == 128 ? 3 : 0;
-    constexpr int XV = IN / 64;                  // float4 per thread per x tile
+    constexpr int NLDS = IN == 128 ? BAND_NLDS : 0;
+    constexpr int XV = IN / 64;                  // 16-byte units per thread per x tile
     __shared__ __attribute__((aligned(16))) _Float16 xpl[2][2][IN * 16];     // [slot][piece][k / 8][seq][8]
     __shared__ __attribute__((aligned(16))) _Float16 hpl[2][2][HID * 16];
     __shared__ __attribute__((aligned(16))) uint4 w2lds[NLDS ? 4 * NLDS * 4 * 64 : 1];
+    __shared__ __attribute__((aligned(16))) float bias_lds[4 * HID];         // this direction's b_ih + b_hh, [gate][unit]
 
     const int dir = blockIdx.y;
     const int n0 = blockIdx.x * 16;
@@ -230,59 +243,86 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
                         w[b][gte][pc] = __builtin_bit_cast(h8v, v);
                 }
     }
-    float bs[4];
+    bias_lds[tid] = bias[dir * 256 + tid];
+    // The loads above are still in flight when the step loop starts, and the compiler's wait-count bookkeeping merges
+    // that state into the loop (it waited for vmcnt(0), i.e. for the x prefetch of the same step, in front of the last
+    // recurrent MFMA of every step).  A use of every resident register here makes the waits happen once, up front.
 #pragma unroll
-    for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[dir * 256 + gte * 64 + 16 * wave + l15];
-    v4f cv = {0.f, 0.f, 0.f, 0.f};               // cell states of this lane's four (sequence, unit) cells
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) {
+            asm volatile("" : "+v"(w[b][gte][0]));
+            if (b < NB - NLDS) asm volatile("" : "+v"(w[b][gte][1]));
+        }
+    v4f cv = {0.f, 0.f, 0.f, 0.f};               // cell states of this lane's four (unit, sequence) cells
 
-    // x staging: XV float4 per thread: (row, 4 consecutive columns) -> 8 bytes of each piece
-    const int xr_row[2] = {(tid * XV) / (IN / 4), (tid * XV + 1) / (IN / 4)};
-    const int xr_c4[2] = {(tid * XV) % (IN / 4), (tid * XV + 1) % (IN / 4)};
-    auto xload = [&](int t, float4* dst) {
+    // x staging, one 16-byte unit per thread and i < XV.
+    //   layer 0 (fp32 rows of 64): (row, 4 consecutive columns) -> 8 bytes of each piece, split here;
+    //   layer 1 (planes of 2 x 128 halves per (sequence, step)): (row, piece, 8 consecutive k) -> copied as they are.
+    int xrow[XV], xcol[XV];                      // row of the tile, 16-byte column inside the row
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int u = tid + 256 * i;
+        xrow[i] = PLANES_IN ? u >> 5 : u >> 4;
+        xcol[i] = PLANES_IN ? u & 31 : u & 15;
+    }
+    auto xload = [&](int t, u4v* dst) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
-            int row = n0 + xr_row[i];
+            int row = n0 + xrow[i];
             row = row < N ? row : N - 1;
-            dst[i] = *reinterpret_cast<const float4*>(xin + ((size_t)row * L + t) * IN + 4 * xr_c4[i]);
+            dst[i] = *reinterpret_cast<const u4v*>(xin + ((size_t)row * L + t) * IN + 4 * xcol[i]);
         }
     };
-    float amax = 0.f;                            // range guard: largest |x| this thread staged
-    auto xstore = [&](int slot, const float4* src) {
+    float amax = 0.f;                            // range guard: largest |x| this thread staged (layer 0; |h| < 1)
+    auto xstore = [&](int slot, const u4v* src) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
-            const float v[4] = {src[i].x, src[i].y, src[i].z, src[i].w};
-            h4v p0, p1;
+            if (PLANES_IN) {
+                const int piece = xcol[i] >> 4, k8 = xcol[i] & 15;
+                *reinterpret_cast<u4v*>(&xpl[slot][piece][(k8 * 16 + xrow[i]) * 8]) = src[i];
+            } else {
+                const v4f v = __builtin_bit_cast(v4f, src[i]);
+                h4v p0, p1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                amax = __builtin_fmaxf(amax, __builtin_fabsf(v[e]));
-                const float cl = __builtin_fminf(__builtin_fmaxf(v[e], -65504.f), 65504.f);
-                _Float16 a, b2;
-                split_h2(cl, a, b2);
-                p0[e] = a; p1[e] = b2;
+                for (int e = 0; e < 4; ++e) {
+                    amax = __builtin_fmaxf(amax, __builtin_fabsf(v[e]));
+                    const float cl = __builtin_fminf(__builtin_fmaxf(v[e], -65504.f), 65504.f);
+                    _Float16 a, b2;
+                    split_h2(cl, a, b2);
+                    p0[e] = a; p1[e] = b2;
+                }
+                const int o = ((xcol[i] >> 1) * 16 + xrow[i]) * 8 + (xcol[i] & 1) * 4;
+                *reinterpret_cast<h4v*>(&xpl[slot][0][o]) = p0;
+                *reinterpret_cast<h4v*>(&xpl[slot][1][o]) = p1;
             }
-            const int o = ((xr_c4[i] >> 1) * 16 + xr_row[i]) * 8 + (xr_c4[i] & 1) * 4;
-            *reinterpret_cast<h4v*>(&xpl[slot][0][o]) = p0;
-            *reinterpret_cast<h4v*>(&xpl[slot][1][o]) = p1;
         }
     };
     auto tmap = [&](int step) { return dir ? L - 1 - step : step; };
 
-    // the first k block of a step starts from a zero C operand (an inline constant: no accumulator initialisation),
-    // the bias joins in the cell update
+    // Gate pre-activations as D^T = W X^T: the weights are the MFMA's A operand (row = unit), the activations its B operand
+    // (column = sequence), so accumulator register r of lane (l15, q) is unit 16 wave + 4 q + r of sequence l15: the four
+    // values a lane produces per step are CONSECUTIVE units of one sequence - one 8-byte LDS write per piece and one
+    // 16-byte global store per step instead of four scattered ones each (the cell update is bound by instruction
+    // issue: ~8 clocks per instruction of a lone wave, tools/mfma_valu_overlap.hip).
+    // The first k block of a step starts from the bias (C operand read from LDS), the second accumulator from zero.
     v4f hi[4], lo[4];
     const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
     const int frag = (q * 16 + l15) * 8;         // this lane's 16-byte unit inside a 32-deep block of a plane
+    const float* const bias_l = &bias_lds[16 * wave + 4 * q];
     auto block_mfma = [&](const int b, const h8v a0, const h8v a1) {
         h8v w2[4];
 #pragma unroll
         for (int gte = 0; gte < 4; ++gte)
             w2[gte] = b >= NB - NLDS ? __builtin_bit_cast(h8v, w2lds[((wave * NLDS + (b - (NB - NLDS))) * 4 + gte) * 64 + lane]) : w[b][gte][1];
+        if (BAND_ABL & 16) { asm volatile("" :: "v"(a0), "v"(a1), "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3])); return; }
 #pragma unroll
-        for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w[b][gte][0], b == 0 ? zero4 : hi[gte], 0, 0, 0);
+        for (int gte = 0; gte < 4; ++gte)
+            hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b][gte][0], a0, b == 0 ? *reinterpret_cast<const v4f*>(bias_l + gte * HID) : hi[gte], 0, 0, 0);
 #pragma unroll
-        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, w[b][gte][0], b == 0 ? zero4 : lo[gte], 0, 0, 0);
+        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b][gte][0], a1, b == 0 ? zero4 : lo[gte], 0, 0, 0);
 #pragma unroll
-        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, w2[gte], lo[gte], 0, 0, 0);
+        for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[gte], a0, lo[gte], 0, 0, 0);
     };
     // fragments one block ahead of the MFMAs; the scheduling fences keep the compiler from hoisting every block's
     // ds_reads to the top (register pressure: the 128-input layer sits at the 256-VGPR limit of 2 waves per SIMD)
@@ -319,52 +359,66 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
 
     {   // prologue: h_{-1} = 0 (slot 1), x of the first two steps, input half of step 0
         *reinterpret_cast<uint4*>(&hpl[1][0][0] + tid * 8) = make_uint4(0, 0, 0, 0);      // 2 pieces x 1024 halves = 256 x 16 B
-        float4 x0[XV];
+        u4v x0[XV];
         xload(tmap(0), x0);
         xstore(0, x0);
         if (L > 1) { xload(tmap(1), x0); xstore(1, x0); }
     }
+    // x two steps ahead travels in registers: loaded at the END of a step (behind that step's h stores in issue order),
+    // written to LDS in the next one.  The wait in front of that write is then only ever for a load that is a whole step
+    // old; with the load at the top of the step and the write behind the (predicated, i.e. branchy) h stores the compiler
+    // had to wait for vmcnt(0), stores included.
+    u4v xn[XV];              // (a native vector type: an array of HIP's uint4 structs stayed in scratch)
+    if (L > 2) xload(tmap(2), xn);
     __syncthreads();
     x_part(0);
     stamp(0);
 
-    const int unit = 16 * wave + l15;
+    // where this lane's four values of a step go: LDS planes (next step's B operand), global (next layer)
+    const int hoff = ((2 * wave + (q >> 1)) * 16 + l15) * 8 + 4 * (q & 1);
+    const bool row_ok = n0 + l15 < N;
+    const size_t grow = (size_t)(row_ok ? n0 + l15 : 0) * L;
     for (int step = 0; step < L; ++step) {
         const int t = tmap(step);
-        float4 xn[XV];
         const bool more2 = step + 2 < L;
-        if (more2) xload(tmap(step + 2), xn);
 
         h_part((step + 1) & 1);                  // h_{step-1} lives in slot (step - 1) & 1
         stamp(1);
 
-        // cell update; C/D layout of the 16x16 MFMA: col (unit) = lane & 15, row (sequence) = 4*(lane>>4) + reg
-        _Float16* const hp0 = &hpl[step & 1][0][((unit >> 3) * 16) * 8 + (unit & 7)];
-        _Float16* const hp1 = &hpl[step & 1][1][((unit >> 3) * 16) * 8 + (unit & 7)];
-        {   // the four cells of this lane as 4-vectors: the adds / multiplies become v_pk_* (two per instruction),
-            // only the 5 exp + 5 rcp per cell stay scalar
-            const v4f pi = (hi[0] + lo[0] * (1.f / 2048.f)) + bs[0], pf = (hi[1] + lo[1] * (1.f / 2048.f)) + bs[1];
-            const v4f pg = (hi[2] + lo[2] * (1.f / 2048.f)) + bs[2], po = (hi[3] + lo[3] * (1.f / 2048.f)) + bs[3];
+        {   // cell update on 4-vectors (the adds / multiplies become v_pk_*, only the 5 exp + 5 rcp per cell stay scalar)
+            const v4f pi = hi[0] + lo[0] * (1.f / 2048.f), pf = hi[1] + lo[1] * (1.f / 2048.f);
+            const v4f pg = hi[2] + lo[2] * (1.f / 2048.f), po = hi[3] + lo[3] * (1.f / 2048.f);
             const v4f ig = rcp4(1.0f + exp2_4(pi * -1.44269504f)), fg = rcp4(1.0f + exp2_4(pf * -1.44269504f));
             const v4f gg = 2.0f * rcp4(1.0f + exp2_4(pg * -2.88539008f)) - 1.0f, og = rcp4(1.0f + exp2_4(po * -1.44269504f));
             cv = fg * cv + ig * gg;
             const v4f hv4 = og * (2.0f * rcp4(1.0f + exp2_4(cv * -2.88539008f)) - 1.0f);
+            if (more2 && !(BAND_ABL & 1)) xstore(step & 1, xn);         // slot of x_step, whose readers finished before the last barrier
+            h4v p0, p1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float hv = hv4[r];
-                const int m = 4 * q + r;
-                _Float16 p0, p1;
-                split_h2(hv, p0, p1);
-                hp0[m * 8] = p0;
-                hp1[m * 8] = p1;
-                if (n0 + m < N) hout[((size_t)(n0 + m) * L + t) * (2 * HID) + dir * HID + unit] = hv;
+                _Float16 a, b2;
+                split_h2(hv4[r], a, b2);
+                p0[r] = a; p1[r] = b2;
+            }
+            if (!(BAND_ABL & 4)) {
+                *reinterpret_cast<h4v*>(&hpl[step & 1][0][hoff]) = p0;
+                *reinterpret_cast<h4v*>(&hpl[step & 1][1][hoff]) = p1;
+            }
+            if (row_ok && !(BAND_ABL & 2)) {
+                if (PLANES_OUT) {
+                    _Float16* const hp = reinterpret_cast<_Float16*>(hout) + ((grow + t) * 2) * (2 * HID) + dir * HID + 16 * wave + 4 * q;
+                    *reinterpret_cast<h4v*>(hp) = p0;
+                    *reinterpret_cast<h4v*>(hp + 2 * HID) = p1;
+                } else {
+                    *reinterpret_cast<v4f*>(hout + (grow + t) * (2 * HID) + dir * HID + 16 * wave + 4 * q) = hv4;
+                }
             }
         }
+        if (step + 3 < L) xload(tmap(step + 3), xn);
         stamp(2);
         if (step + 1 < L) x_part((step + 1) & 1);
-        if (more2) xstore(step & 1, xn);         // slot of x_step, whose readers finished before the last barrier
         stamp(3);
-        __syncthreads();
+        if (!(BAND_ABL & 8)) __syncthreads();
         stamp(4);
     }
     if (!(amax <= 65504.f) && range_flag) *range_flag = 1;

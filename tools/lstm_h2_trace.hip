@@ -1,10 +1,29 @@
 // Measurement-only: phase breakdown of the fp16x2 band / time LSTM kernels (100 MHz stamps inside the kernels).
 //   hipcc -O3 --offload-arch=gfx950 -o build/lstm_h2_trace tools/lstm_h2_trace.hip
 #include "../speechseparation_amd/csrc/lstm.hip"
+#include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 using namespace bsrnn;
+// own generator: rand() is shared with the HIP runtime's threads, which made the inputs differ from process to process
+static unsigned g_seed = 12345u;
+static int lcg() { g_seed = g_seed * 1664525u + 1013904223u; return (int)((g_seed >> 8) & 0x7fffff); }
+#define rand lcg
+#undef RAND_MAX
+#define RAND_MAX 0x7fffff
+namespace bsrnn { bool force_f32() { return false; } }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// fills every CU's LDS (and a few registers) with a pattern: a kernel that reads LDS it did not write shows up as a
+// run-to-run difference when the pattern changes between two otherwise identical launches
+__global__ __launch_bounds__(256) void pollute_lds(unsigned pat, unsigned* sink)
+{
+    __shared__ unsigned buf[18 * 1024];          // 72 KB: two workgroups per CU cover 144 KB
+    for (int i = threadIdx.x; i < 18 * 1024; i += 256) buf[i] = pat ^ (i * 2654435761u);
+    __syncthreads();
+    if (buf[(threadIdx.x * 97) % (18 * 1024)] == 0x12345u) sink[0] = 1;
+}
 
 template <int IN>
 static int run_band(int N, int L)
@@ -19,6 +38,10 @@ static int run_band(int N, int L)
     for (auto& v : hx) v = (rand() / (float)RAND_MAX - 0.5f);
     std::vector<uint16_t> hw(nw);
     for (auto& v : hw) v = (uint16_t)(0x2c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));   // fp16 in +-[0.06, 0.12)
+    if (IN == 128) {                             // layer 1 reads the fp16 planes layer 0 writes: random halves in +-[0.06, 0.12)
+        uint16_t* px = reinterpret_cast<uint16_t*>(hx.data());
+        for (size_t i = 0; i < 2 * nx; ++i) px[i] = (uint16_t)(0x2c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
+    }
     CK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice));
     CK(hipMemset(b, 0, 512 * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -29,6 +52,38 @@ static int run_band(int N, int L)
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("band_lstm_h2<%d> N=%d L=%d launch %d: %.1f us\n", IN, N, L, rep, ms * 1e3);
+    }
+    {   // determinism: the same launch again into a second buffer, compared word for word
+        float* h2b; CK(hipMalloc(&h2b, nh * 4));
+        std::vector<uint32_t> ha(nh), hb(nh);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipLaunchKernelGGL(pollute_lds, dim3(2048), dim3(256), 0, 0, 0x7fc00000u + rep, (unsigned*)dbg);
+            hipLaunchKernelGGL((band_lstm_h2_kernel<IN, false>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, (int*)nullptr, dbg);
+            hipLaunchKernelGGL(pollute_lds, dim3(2048), dim3(256), 0, 0, 0x3c003c00u + rep, (unsigned*)dbg);
+            hipLaunchKernelGGL((band_lstm_h2_kernel<IN, false>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h2b, (const uint4*)w, b, N, L, (int*)nullptr, dbg);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(ha.data(), h, nh * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hb.data(), h2b, nh * 4, hipMemcpyDeviceToHost));
+            size_t nd = 0;
+            for (size_t i = 0; i < nh; ++i)
+                if (ha[i] != hb[i]) {
+                    if (nd < 12) {
+                        const size_t u = i % 128, tt = (i / 128) % L, n = i / 128 / L;
+                        float fa, fb; memcpy(&fa, &ha[i], 4); memcpy(&fb, &hb[i], 4);
+                        printf("    differ: seq %zu (tile %zu row %zu) t %zu dir %zu unit %zu: %.9g vs %.9g\n", n, n / 16, n % 16, tt, u / 64, u % 64, fa, fb);
+                    }
+                    ++nd;
+                }
+            printf("  rerun %d: %zu of %zu words differ\n", rep, nd, nh);
+        }
+        CK(hipFree(h2b));
+    }
+    {   // checksum of the output (to compare builds bit for bit)
+        std::vector<uint32_t> hh(nh);
+        CK(hipMemcpy(hh.data(), h, nh * 4, hipMemcpyDeviceToHost));
+        uint64_t acc = 1469598103934665603ull;
+        for (uint32_t v : hh) acc = (acc ^ v) * 1099511628211ull;
+        printf("  output hash %016llx\n", (unsigned long long)acc);
     }
     unsigned long long hd[4 * 4 * 5];
     CK(hipMemcpy(hd, dbg, sizeof hd, hipMemcpyDeviceToHost));
