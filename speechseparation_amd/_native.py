@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbsrnn_hip.so")
+# BSRNN_HIP_LIB: another build of the same library (A/B measurements of kernel variants); default: the in-tree build
+LIB_PATH = os.environ.get("BSRNN_HIP_LIB") or os.path.join(_HERE, "lib", "libbsrnn_hip.so")
 
 # Every symbol include/bsrnn_hip.h declares (tests/test_abi.py checks header == this list == the .so)
 SYMBOLS = [

@@ -289,8 +289,9 @@ template <> struct Piece<2> {
     // a - a1 and the scaling are exact in fp32, so the fused form fma(-a1, 2048, 2048 a) rounds once, to the same value as
     // convert-back / subtract / multiply / convert - two VALU instructions per element (v_pk_mul_f32 + v_fma_mix{lo,hi}_f16).
     // |a| > 65504 makes a1 infinite: callers track max |a| and raise the range flag (the result is invalid either way).
-    static __device__ __forceinline__ void split(const v4f a, T4* p)
+    static __device__ __forceinline__ void split(v4f a, T4* p)
     {
+        asm("" : "+v"(a));       // split the fp32 value itself, whatever produced it (lstm.hip, split_h2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[0][i] = (_Float16)a[i];
 #pragma unroll

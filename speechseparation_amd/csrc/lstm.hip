@@ -17,7 +17,13 @@
 #include <cstring>
 
 #ifndef BAND_NLDS
-#define BAND_NLDS 3
+#define BAND_NLDS 2                 // second-piece weight blocks of the 128-input layer kept in LDS (3: 226 VGPRs, 2: 242, 1: 254)
+#endif
+#ifndef BAND_BIAS_LAST
+#define BAND_BIAS_LAST 0
+#endif
+#ifndef BAND_NO_PLANES
+#define BAND_NO_PLANES 0
 #endif
 #ifndef BAND_ABL
 #define BAND_ABL 0                // measurement only (tools/lstm_h2_trace.hip): bit 1 no x staging, 2 no global h store, 4 no h publish, 8 no step barrier, 16 no MFMAs, 32 no transcendentals
@@ -193,10 +199,16 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split_h2(const float v, _Float16& p0, _Float16& p1)
+__device__ __forceinline__ void split_h2(float v, _Float16& p0, _Float16& p1)
 {
+    // The value is split AS the fp32 number it is: the empty asm hides its producer from the optimiser.  Without it the
+    // compiler fused the producing multiply into ONE of the two conversions (v_fma_mixlo_f16 of the unrounded product for
+    // the residual, v_cvt_pk_f16_f32 of the rounded product for the stored piece): in the rare double-rounding cases the
+    // two first pieces differ by one fp16 ulp and hi + lo / 2048 is off by 2^-11 |v| (seen as 1e-5 errors of single
+    // sequences when the planes went to the next layer; tools/precision_dual_path.py).
+    asm("" : "+v"(v));
     p0 = (_Float16)v;
-    p1 = (_Float16)((v - (float)p0) * 2048.f);
+    p1 = (_Float16)__builtin_fmaf(-(float)p0, 2048.f, v * 2048.f);      // = 2048 (v - p0), exact before the conversion: one v_fma_mixlo_f16
 }
 
 template <int IN, bool TRACE = false>
@@ -209,11 +221,11 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
     if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
     constexpr int NBX = IN / 32, NBH = HID / 32, NB = NBX + NBH;
-    constexpr bool PLANES_IN = IN == 2 * HID;    // layer 1: x arrives as the fp16 planes layer 0 wrote
-    constexpr bool PLANES_OUT = IN == HID;       // layer 0: h leaves as fp16 planes (read by layer 1 only)
+    constexpr bool PLANES_IN = IN == 2 * HID && !BAND_NO_PLANES;    // layer 1: x arrives as the fp16 planes layer 0 wrote
+    constexpr bool PLANES_OUT = IN == HID && !BAND_NO_PLANES;       // layer 0: h leaves as fp16 planes (read by layer 1 only)
     // blocks whose second weight piece lives in LDS instead of VGPRs (counted from the last k block): the 128-input
-    // layer would need 192 weight + 32 accumulator registers; with 3 blocks (both of W_hh, the last of W_ih) in LDS
-    // it is 144 + 32 and compiles without scratch (measured with spills: 1.9 us of every 3.5 us step in reloads)
+    // layer would need 192 weight + 32 accumulator registers; with the two W_hh blocks in LDS it is 160 + 32 and
+    // compiles without scratch at 242 VGPRs (measured with spills: 1.9 us of every 3.5 us step in reloads)
     constexpr int NLDS = IN == 128 ? BAND_NLDS : 0;
     constexpr int XV = IN / 64;                  // 16-byte units per thread per x tile
     __shared__ __attribute__((aligned(16))) _Float16 xpl[2][2][IN * 16];     // [slot][piece][k / 8][seq][8]
@@ -263,8 +275,8 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
         const int u = tid + 256 * i;
-        xrow[i] = PLANES_IN ? u >> 5 : u >> 4;
-        xcol[i] = PLANES_IN ? u & 31 : u & 15;
+        xrow[i] = u / (IN / 4);                  // IN / 4 units per row in both formats
+        xcol[i] = u % (IN / 4);
     }
     auto xload = [&](int t, u4v* dst) {
 #pragma unroll
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         if (BAND_ABL & 16) { asm volatile("" :: "v"(a0), "v"(a1), "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3])); return; }
 #pragma unroll
         for (int gte = 0; gte < 4; ++gte)
-            hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b][gte][0], a0, b == 0 ? *reinterpret_cast<const v4f*>(bias_l + gte * HID) : hi[gte], 0, 0, 0);
+            hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b][gte][0], a0, b == 0 ? (BAND_BIAS_LAST ? zero4 : *reinterpret_cast<const v4f*>(bias_l + gte * HID)) : hi[gte], 0, 0, 0);
 #pragma unroll
         for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b][gte][0], a1, b == 0 ? zero4 : lo[gte], 0, 0, 0);
 #pragma unroll
@@ -386,8 +398,12 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         stamp(1);
 
         {   // cell update on 4-vectors (the adds / multiplies become v_pk_*, only the 5 exp + 5 rcp per cell stay scalar)
-            const v4f pi = hi[0] + lo[0] * (1.f / 2048.f), pf = hi[1] + lo[1] * (1.f / 2048.f);
-            const v4f pg = hi[2] + lo[2] * (1.f / 2048.f), po = hi[3] + lo[3] * (1.f / 2048.f);
+            v4f pi = hi[0] + lo[0] * (1.f / 2048.f), pf = hi[1] + lo[1] * (1.f / 2048.f);
+            v4f pg = hi[2] + lo[2] * (1.f / 2048.f), po = hi[3] + lo[3] * (1.f / 2048.f);
+            if (BAND_BIAS_LAST) {
+                pi += *reinterpret_cast<const v4f*>(bias_l); pf += *reinterpret_cast<const v4f*>(bias_l + HID);
+                pg += *reinterpret_cast<const v4f*>(bias_l + 2 * HID); po += *reinterpret_cast<const v4f*>(bias_l + 3 * HID);
+            }
             const v4f ig = rcp4(1.0f + exp2_4(pi * -1.44269504f)), fg = rcp4(1.0f + exp2_4(pf * -1.44269504f));
             const v4f gg = 2.0f * rcp4(1.0f + exp2_4(pg * -2.88539008f)) - 1.0f, og = rcp4(1.0f + exp2_4(po * -1.44269504f));
             cv = fg * cv + ig * gg;

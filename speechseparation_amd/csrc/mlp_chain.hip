@@ -67,9 +67,11 @@ constexpr int PD = CHAIN_PD;
 #define CHAIN_PD48 4               // prefetch depth of the 48-row geometry (its k-steps carry two tiles' fragments)
 #endif
 
-__device__ __forceinline__ void split4(const v4f a, h4& p0, h4& p1)
+__device__ __forceinline__ void split4(v4f a, h4& p0, h4& p1)
 {
-    // identical to Piece<2>::split of gemm.hip: a1 = fp16(a), a2 = fp16(fma(-a1, 2048, 2048 a))
+    // identical to Piece<2>::split of gemm.hip: a1 = fp16(a), a2 = fp16(fma(-a1, 2048, 2048 a)); the empty asm keeps the
+    // compiler from fusing a's producer into one of the two conversions (lstm.hip, split_h2)
+    asm("" : "+v"(a));
 #pragma unroll
     for (int i = 0; i < 4; ++i) p0[i] = (_Float16)a[i];
 #pragma unroll

@@ -2,7 +2,10 @@
 //   hipcc -O3 --offload-arch=gfx950 -o build/lstm_h2_trace tools/lstm_h2_trace.hip
 #include "../speechseparation_amd/csrc/lstm.hip"
 #include <cstdint>
+#include <cmath>
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 using namespace bsrnn;
@@ -43,15 +46,59 @@ static int run_band(int N, int L)
         for (size_t i = 0; i < 2 * nx; ++i) px[i] = (uint16_t)(0x2c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
     }
     CK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), nw * 2, hipMemcpyHostToDevice));
-    CK(hipMemset(b, 0, 512 * 4));
+    std::vector<float> hbias(512);
+    for (auto& v : hbias) v = (rand() / (float)RAND_MAX - 0.5f) * 0.5f;
+    CK(hipMemcpy(b, hbias.data(), 512 * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, 0));
-        if (rep == 3) hipLaunchKernelGGL((band_lstm_h2_kernel<IN, true>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, (int*)nullptr, dbg);
-        else hipLaunchKernelGGL((band_lstm_h2_kernel<IN, false>), dim3((N + 15) / 16, 2), dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, (int*)nullptr, dbg);
+        const int per_wg = getenv("BAND_TILES") ? atoi(getenv("BAND_TILES")) : 1;        // tiles per workgroup
+        const dim3 grid(((N + 15) / 16 + per_wg - 1) / per_wg, 2);
+        if (rep == 3) hipLaunchKernelGGL((band_lstm_h2_kernel<IN, true>), grid, dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, (int*)nullptr, dbg);
+        else hipLaunchKernelGGL((band_lstm_h2_kernel<IN, false>), grid, dim3(256), 0, 0, x, h, (const uint4*)w, b, N, L, (int*)nullptr, dbg);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("band_lstm_h2<%d> N=%d L=%d launch %d: %.1f us\n", IN, N, L, rep, ms * 1e3);
+    }
+    {   // accuracy: a few sequences against a double-precision evaluation of the same layer (weights = w1 + w2 / 2048)
+        auto h2f = [](uint16_t b) { _Float16 v; memcpy(&v, &b, 2); return (double)(float)v; };
+        std::vector<uint32_t> hh(nh);
+        CK(hipMemcpy(hh.data(), h, nh * 4, hipMemcpyDeviceToHost));
+        const uint16_t* hp = reinterpret_cast<const uint16_t*>(hh.data());
+        const uint16_t* px = reinterpret_cast<const uint16_t*>(hx.data());
+        double worst = 0;
+        for (int n : {0, 5, 17, N - 1})
+            for (int dir = 0; dir < 2; ++dir) {
+                std::vector<double> hprev(64, 0.0), c(64, 0.0), xh(IN + 64), hnew(64);
+                for (int sstep = 0; sstep < L; ++sstep) {
+                    const int t = dir ? L - 1 - sstep : sstep;
+                    for (int k = 0; k < IN; ++k)
+                        xh[k] = IN == 128 ? h2f(px[(((size_t)n * L + t) * 2 + 0) * 128 + k]) + h2f(px[(((size_t)n * L + t) * 2 + 1) * 128 + k]) / 2048.0
+                                          : (double)hx[((size_t)n * L + t) * IN + k];
+                    for (int k = 0; k < 64; ++k) xh[IN + k] = hprev[k];
+                    for (int u = 0; u < 64; ++u) {
+                        double pre[4];
+                        for (int g = 0; g < 4; ++g) {
+                            double a = 0;
+                            for (int k = 0; k < IN + 64; ++k) {
+                                const int blk = k / 32, kb = (k % 32) / 8, j = k % 8, wv = u / 16, ln = (u % 16) + 16 * kb;
+                                const size_t base = ((((size_t)(dir * 4 + wv) * NB * 4 * 2) + (blk * 4 + g) * 2) * 64 + ln) * 8 + j;
+                                a += (h2f(hw[base]) + h2f(hw[base + 64 * 8]) / 2048.0) * xh[k];
+                            }
+                            pre[g] = a + (double)hbias[dir * 256 + g * 64 + u];
+                        }
+                        const double ig = 1 / (1 + exp(-pre[0])), fg = 1 / (1 + exp(-pre[1])), gg = tanh(pre[2]), og = 1 / (1 + exp(-pre[3]));
+                        c[u] = fg * c[u] + ig * gg;
+                        hnew[u] = og * tanh(c[u]);
+                        double got;
+                        if (IN == 64) got = h2f(hp[(((size_t)n * L + t) * 2 + 0) * 128 + dir * 64 + u]) + h2f(hp[(((size_t)n * L + t) * 2 + 1) * 128 + dir * 64 + u]) / 2048.0;
+                        else { float f; memcpy(&f, &hh[((size_t)n * L + t) * 128 + dir * 64 + u], 4); got = f; }
+                        worst = std::max(worst, fabs(got - hnew[u]));
+                    }
+                    hprev = hnew;
+                }
+            }
+        printf("  max |kernel - double reference| over 4 sequences x 2 directions: %.3e\n", worst);
     }
     {   // determinism: the same launch again into a second buffer, compared word for word
         float* h2b; CK(hipMalloc(&h2b, nh * 4));
@@ -137,6 +184,8 @@ static int run_time(int R, int T, int K)
 
 int main()
 {
+    if (run_band<64>(72, 12)) return 1;
+    if (run_band<128>(72, 12)) return 1;
     if (run_band<64>(8064, 12)) return 1;
     if (run_band<128>(8064, 12)) return 1;
     if (run_band<128>(256, 12)) return 1;       // a single round of workgroups, 1 per CU
