@@ -140,6 +140,29 @@ int  bsrnn_dual_path(bsrnn_ctx* ctx, const float* z_dev, float* z_out_dev,
                      const float* state_in_dev, float* state_out_dev,
                      int32_t C, int32_t T, void* stream);
 
+/* ---- training step, part 1: the recurrent layers ------------------------------------------
+ * The reference trains with torch.autograd (train.py:97-115: `loss.backward()`, `optimizer.step()`); a replacement has to
+ * provide the backward pass itself.  These two calls are one `nn.LSTM` layer of NormRNNResidual (bsrnn.py:66-72) with
+ * `ndir` directions (2 = bidirectional: direction 1 uses torch's `_reverse` weights and runs the sequence backwards) over
+ * N sequences of L steps, zero initial state, exact fp32:
+ *   the band-axis BLSTM is N = C*T, L = K, ndir = 2 (bsrnn.py:144-150), the time-axis LSTM N = C*K, L = T, ndir = 1 with the
+ *   rows gathered as in bsrnn.py:110-113.
+ * All pointers are device memory.  Weights in torch layout: w_ih [ndir][256][IN] (IN = 64 | 128), w_hh [ndir][256][64],
+ * gate order i,f,g,o; bias [ndir][256] = b_ih + b_hh.
+ *   forward : x [N][L][IN] -> h [N][L][ndir*64]; gates [N][L][ndir][256] (after sigmoid / tanh) and cells [N][L][ndir][64]
+ *             are what backward reads.
+ *   backward: dh [N][L][ndir*64] = gradient of the loss w.r.t. h  ->  dx [N][L][IN] (NULL: not wanted), dw_ih, dw_hh in the
+ *             weights' layouts, db [ndir][256] (= the gradient of b_ih and of b_hh).  Gradients are overwritten, not
+ *             accumulated; sums run in a fixed order (bit-reproducible).  Workspace is taken from the device's
+ *             stream-ordered pool for the duration of the call. */
+int  bsrnn_lstm_train_forward(bsrnn_ctx* ctx, const float* x_dev, const float* w_ih_dev, const float* w_hh_dev,
+                              const float* bias_dev, float* h_dev, float* gates_dev, float* cells_dev,
+                              int32_t N, int32_t L, int32_t IN, int32_t ndir, void* stream);
+int  bsrnn_lstm_train_backward(bsrnn_ctx* ctx, const float* x_dev, const float* h_dev, const float* gates_dev,
+                               const float* cells_dev, const float* dh_dev, const float* w_ih_dev, const float* w_hh_dev,
+                               float* dx_dev, float* dw_ih_dev, float* dw_hh_dev, float* db_dev,
+                               int32_t N, int32_t L, int32_t IN, int32_t ndir, void* stream);
+
 /* ---- the STFT sandwich of the callers --------------------------------------------------
  * bsrnn_stft   = infer.py:29-33 (dup. m_dataset.py:187-190): wave_dev [R, n] ->
  *                x_dev [R, 2050, T], T = 1 + n/1024; periodic Hann 2048, hop 1024,

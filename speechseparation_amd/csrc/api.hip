@@ -1197,6 +1197,56 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
     return 0;
 }
 
+// --------------------------------------------------------------------------- training step, part 1: recurrent layers
+// nn.LSTM of NormRNNResidual (bsrnn.py:66-72) forward with saves and backward through time (lstm_train.hip); what
+// loss.backward() runs for these layers in train.py:97-115.  Operands are the caller's device buffers (torch layouts);
+// nothing of the committed inference weights is used.
+static int train_args_ok(bsrnn_ctx* c, int32_t N, int32_t L, int32_t IN, int32_t ndir, const char* who)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    if (N < 1 || L < 1 || (IN != HID && IN != 2 * HID) || ndir < 1 || ndir > 2 || (int64_t)N * L > (int64_t)1 << 30)
+        return fail(BSRNN_EARG, "%s: need N, L >= 1, IN = 64 | 128, ndir = 1 | 2 (got N=%d L=%d IN=%d ndir=%d)", who, N, L, IN, ndir);
+    return 0;
+}
+
+int bsrnn_lstm_train_forward(bsrnn_ctx* c, const float* x, const float* w_ih, const float* w_hh, const float* bias, float* h,
+                             float* gates, float* cells, int32_t N, int32_t L, int32_t IN, int32_t ndir, void* stream)
+{
+    int rc = train_args_ok(c, N, L, IN, ndir, "bsrnn_lstm_train_forward");
+    if (rc) return rc;
+    if (!x || !w_ih || !w_hh || !bias || !h || !gates || !cells) return fail(BSRNN_EARG, "bsrnn_lstm_train_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    launch_lstm_train_forward(x, w_ih, w_hh, bias, h, gates, cells, N, L, IN, ndir, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_lstm_train_backward(bsrnn_ctx* c, const float* x, const float* h, const float* gates, const float* cells, const float* dh,
+                              const float* w_ih, const float* w_hh, float* dx, float* dw_ih, float* dw_hh, float* db,
+                              int32_t N, int32_t L, int32_t IN, int32_t ndir, void* stream)
+{
+    int rc = train_args_ok(c, N, L, IN, ndir, "bsrnn_lstm_train_backward");
+    if (rc) return rc;
+    if (!x || !h || !gates || !cells || !dh || !w_ih || !w_hh || !dw_ih || !dw_hh || !db)
+        return fail(BSRNN_EARG, "bsrnn_lstm_train_backward: null argument (only dx may be null)");
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    // workspace in stream order: gate gradients of every (sequence, step, direction) + the partial sums of the reductions
+    const size_t n_dg = (size_t)N * L * ndir * 256, n_scr = lstm_train_scratch_floats(IN, ndir);
+    float* ws = nullptr;
+    if (hipMallocAsync((void**)&ws, (n_dg + n_scr) * sizeof(float), s) != hipSuccess || !ws) {
+        (void)hipGetLastError();
+        return fail(BSRNN_EHIP, "bsrnn_lstm_train_backward: out of device memory (%zu MB of workspace)", (n_dg + n_scr) * sizeof(float) >> 20);
+    }
+    launch_lstm_train_backward(x, h, gates, cells, dh, w_ih, w_hh, ws, ws + n_dg, dx, dw_ih, dw_hh, db, N, L, IN, ndir, s);
+    const hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(ws, s);
+    if (e != hipSuccess) return fail(BSRNN_EHIP, "bsrnn_lstm_train_backward: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // --------------------------------------------------------------------------- STFT sandwich
 int bsrnn_stft(bsrnn_ctx* c, const float* wave, float* x, int32_t R, int64_t n, void* stream)
 {

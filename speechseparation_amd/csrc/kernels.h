@@ -130,6 +130,20 @@ int lstm_mode();
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream);
 
+// ------------------------------------------------------------------ training step, part 1: recurrent layers (lstm_train.hip)
+// One nn.LSTM layer (bsrnn.py:66-72) with ndir directions over N sequences of L steps, exact fp32; weights in torch layout
+// (w_ih [ndir][256][IN], w_hh [ndir][256][64], bias [ndir][256] = b_ih + b_hh), zero initial state.
+//   forward:  x [N][L][IN] -> h [N][L][ndir 64], gates [N][L][ndir][256] (after the non-linearities), cells [N][L][ndir][64]
+//   backward: dh [N][L][ndir 64] -> dx [N][L][IN] (or null), dw_ih, dw_hh, db (= db_ih = db_hh) in the weights' layouts;
+//             dg [N][L][ndir][256] and scratch [lstm_train_scratch_floats] are workspace
+constexpr int LSTM_TRAIN_CHUNKS = 64;        // row chunks of the weight-gradient reductions (summed in a fixed order)
+size_t lstm_train_scratch_floats(int IN, int ndir);
+void launch_lstm_train_forward(const float* x, const float* w_ih, const float* w_hh, const float* bias, float* h, float* gates,
+                               float* cells, int N, int L, int IN, int ndir, hipStream_t stream);
+void launch_lstm_train_backward(const float* x, const float* h, const float* gates, const float* cells, const float* dh,
+                                const float* w_ih, const float* w_hh, float* dg, float* scratch, float* dx, float* dw_ih,
+                                float* dw_hh, float* db, int N, int L, int IN, int ndir, hipStream_t stream);
+
 // ------------------------------------------------------------------ STFT / iSTFT / layout
 struct FftTables {           // device tables, built once per context (double precision on host)
     const float2* tw1024;    // exp(-2 pi i k / 1024), k < 1024

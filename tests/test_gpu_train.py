@@ -1,0 +1,96 @@
+"""GPU: training step, part 1 - the recurrent layers' forward-with-saves and backward through time (csrc/lstm_train.hip,
+bsrnn_lstm_train_forward / _backward) against torch.autograd on stock nn.LSTM on the CPU, the operator the reference's
+train step differentiates (bsrnn.py:66-72 inside train.py:97-115).  Exact-fp32 kernels: outputs to 2e-6, gradients to 1e-4
+of their largest element (sums over up to N*L = 3 000 rows in a different order than torch's)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / max(1e-30, float(b.abs().max())))
+
+
+def _reference(N, L, IN, bidir, seed, gain=1.0):
+    torch.manual_seed(seed)
+    lstm = torch.nn.LSTM(IN, 64, num_layers=1, batch_first=True, bidirectional=bidir)
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.mul_(gain)
+    x = torch.randn(N, L, IN, requires_grad=True)
+    dh = torch.randn(N, L, 128 if bidir else 64)
+    h, _ = lstm(x)
+    (h * dh).sum().backward()
+    return lstm, x, dh, h
+
+
+@pytest.mark.parametrize("N,L,IN,bidir,gain", [
+    (37, 12, 64, True, 1.0),       # band-axis layer 0: 12 bands per sequence, partial tile of sequences
+    (64, 12, 128, True, 3.0),      # band-axis layer 1 (input = both directions of layer 0), saturating gates
+    (24, 126, 64, False, 1.0),     # time-axis layer: C K = 24 sequences of T = 126 frames
+    (1, 1, 64, True, 1.0),         # one sequence, one step
+])
+def test_lstm_layer_forward_and_backward_match_autograd(N, L, IN, bidir, gain):
+    from speechseparation_amd import train
+    lstm, x, dh, h_ref = _reference(N, L, IN, bidir, seed=N + L, gain=gain)
+    w_ih, w_hh, b_ih, b_hh = [t.detach().cuda() for t in train.stack_direction_weights(lstm, 0)]
+    xg = x.detach().cuda()
+    h, gates, cells = train.lstm_layer_forward(xg, w_ih, w_hh, b_ih + b_hh)
+    assert float((h.cpu() - h_ref.detach()).abs().max()) < 2e-6
+    dx, dw_ih, dw_hh, db = train.lstm_layer_backward(xg, h, gates, cells, dh.cuda(), w_ih, w_hh)
+    sfx = ["", "_reverse"][: 2 if bidir else 1]
+    ref = lambda name: torch.stack([getattr(lstm, name + "_l0" + s).grad for s in sfx])     # noqa: E731
+    errs = {"dx": _rel(dx, x.grad), "dw_ih": _rel(dw_ih, ref("weight_ih")), "dw_hh": _rel(dw_hh, ref("weight_hh")),
+            "db": _rel(db, ref("bias_ih"))}
+    print("N=%d L=%d IN=%d ndir=%d: relative gradient errors %s" % (N, L, IN, len(sfx), {k: "%.1e" % v for k, v in errs.items()}))
+    assert max(errs.values()) < 1e-4, errs
+    assert torch.equal(ref("bias_ih"), ref("bias_hh"))          # one db serves both bias vectors
+
+
+def test_autograd_function_stands_in_for_nn_lstm():
+    """Two stacked layers (the 2-layer BLSTM of a band block, bsrnn.py:66-72) through LstmLayerFunction: same loss gradient for
+    every parameter and for the input as stock nn.LSTM."""
+    from speechseparation_amd import train
+    torch.manual_seed(5)
+    lstm = torch.nn.LSTM(64, 64, num_layers=2, batch_first=True, bidirectional=True)
+    x = torch.randn(48, 12, 64, requires_grad=True)
+    target = torch.randn(48, 12, 128)
+    (lstm(x)[0] - target).abs().mean().backward()               # an L1 loss, as the reference's (m_dataset.py:211-216)
+    want = {n: p.grad.clone() for n, p in lstm.named_parameters()}
+    want_dx = x.grad.clone()
+
+    dev = torch.device("cuda:0")
+    params = [[t.detach().to(dev).requires_grad_(True) for t in train.stack_direction_weights(lstm, layer)] for layer in (0, 1)]
+    xg = x.detach().to(dev).requires_grad_(True)
+    y = xg
+    for w in params:
+        y = train.LstmLayerFunction.apply(y, *w)
+    (y - target.to(dev)).abs().mean().backward()
+    assert _rel(xg.grad, want_dx) < 1e-4
+    for layer, w in enumerate(params):
+        for name, t in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), w):
+            for d, sfx in enumerate(("", "_reverse")):
+                assert _rel(t.grad[d], want["%s_l%d%s" % (name, layer, sfx)]) < 1e-4, (name, layer, sfx)
+
+
+def test_backward_is_bit_reproducible_and_validates_arguments():
+    from speechseparation_amd import train
+    from speechseparation_amd._native import NativeError
+    torch.manual_seed(1)
+    x = torch.randn(100, 12, 64, device="cuda")
+    w_ih, w_hh, b = torch.randn(2, 256, 64, device="cuda") * 0.1, torch.randn(2, 256, 64, device="cuda") * 0.1, torch.zeros(2, 256, device="cuda")
+    h, g, c = train.lstm_layer_forward(x, w_ih, w_hh, b)
+    dh = torch.randn_like(h)
+    a = train.lstm_layer_backward(x, h, g, c, dh, w_ih, w_hh)
+    b2 = train.lstm_layer_backward(x, h, g, c, dh, w_ih, w_hh)
+    assert all(torch.equal(u, v) for u, v in zip(a, b2))
+    assert train.lstm_layer_backward(x, h, g, c, dh, w_ih, w_hh, need_dx=False)[0] is None
+    with pytest.raises(ValueError):
+        train.lstm_layer_forward(x, w_ih[:, :, :32], w_hh, b)
+    with pytest.raises(NativeError):
+        train.lstm_layer_forward(torch.randn(4, 3, 96, device="cuda"), torch.randn(1, 256, 96, device="cuda"), w_hh[:1], b[:1])
+    with pytest.raises(ValueError):
+        train.lstm_layer_forward(x.cpu(), w_ih, w_hh, b)
