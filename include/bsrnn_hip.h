@@ -163,6 +163,16 @@ int  bsrnn_lstm_train_backward(bsrnn_ctx* ctx, const float* x_dev, const float* 
                                float* dx_dev, float* dw_ih_dev, float* dw_hh_dev, float* db_dev,
                                int32_t N, int32_t L, int32_t IN, int32_t ndir, void* stream);
 
+/* nn.Linear (+ LeakyReLU(0.01) when leaky != 0) of the per-band MLPs and of fc / fc_in (bsrnn.py:333-376, :69, :74) for the
+ * training step: y = act(x W^T + b), x [M, K] with row stride ldx (a band is a column block of a wider row), W [N, K] torch
+ * layout, y [M, N] with row stride ldy.  Backward: from dy (row stride lddy; and y when leaky) -> dx [M, K] row stride lddx
+ * (NULL: not wanted), dw [N, K], db [N]; overwritten, bit-reproducible.  All device pointers, exact fp32. */
+int  bsrnn_linear_train_forward(bsrnn_ctx* ctx, const float* x_dev, int32_t ldx, const float* w_dev, const float* b_dev,
+                                float* y_dev, int32_t ldy, int32_t M, int32_t K, int32_t N, int32_t leaky, void* stream);
+int  bsrnn_linear_train_backward(bsrnn_ctx* ctx, const float* x_dev, int32_t ldx, const float* w_dev, const float* y_dev,
+                                 int32_t ldy, const float* dy_dev, int32_t lddy, float* dx_dev, int32_t lddx,
+                                 float* dw_dev, float* db_dev, int32_t M, int32_t K, int32_t N, int32_t leaky, void* stream);
+
 /* ---- the STFT sandwich of the callers --------------------------------------------------
  * bsrnn_stft   = infer.py:29-33 (dup. m_dataset.py:187-190): wave_dev [R, n] ->
  *                x_dev [R, 2050, T], T = 1 + n/1024; periodic Hann 2048, hop 1024,

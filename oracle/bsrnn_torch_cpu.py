@@ -93,13 +93,29 @@ class TorchCpuBSRNN:
             parts.append(residual[i] + b)
         return torch.cat(parts, 2)
 
-    @torch.no_grad()
-    def forward(self, x):
-        """[C,2050,T] -> [C,2050,T]"""
+    def forward_differentiable(self, x):
+        """[C,2050,T] -> [C,2050,T] with the autograd graph kept: the reference of the training-step tests (what
+        train.py:97-115 differentiates).  Parameters: `trainable()`."""
         xt = x.permute(0, 2, 1)
         residual, z = self._front(xt)
         z, _ = self._dual_path(z)
         return x * self._back(z, residual).permute(0, 2, 1)
+
+    def trainable(self):
+        """name -> leaf tensor with requires_grad, under the reference's state_dict names."""
+        out = {}
+        for k, t in self.p.items():
+            if ".m.rnn." not in k:
+                out[k] = t.requires_grad_(True)
+        for j, m in enumerate(self.rnn):
+            for k, t in m.named_parameters():
+                out["lstms.%d.m.rnn.%s" % (j, k)] = t
+        return out
+
+    @torch.no_grad()
+    def forward(self, x):
+        """[C,2050,T] -> [C,2050,T]"""
+        return self.forward_differentiable(x)
 
     @torch.no_grad()
     def forward_recurrent(self, x, state):

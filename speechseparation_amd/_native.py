@@ -20,7 +20,7 @@ SYMBOLS = [
     "bsrnn_stream_step", "bsrnn_stream_step_host", "bsrnn_stream_get_state", "bsrnn_set_profiling", "bsrnn_stage_count",
     "bsrnn_stage_name", "bsrnn_stage_times", "bsrnn_dev_alloc", "bsrnn_dev_free", "bsrnn_copy_h2d", "bsrnn_copy_d2h",
     "bsrnn_sync", "bsrnn_evaluate", "bsrnn_io_count", "bsrnn_io_info", "bsrnn_mlp_fused",
-    "bsrnn_lstm_train_forward", "bsrnn_lstm_train_backward",
+    "bsrnn_lstm_train_forward", "bsrnn_lstm_train_backward", "bsrnn_linear_train_forward", "bsrnn_linear_train_backward",
 ]
 METRIC_NAMES = ("loss", "sdr", "input_sdr", "sisdr", "l1_time", "l1_re", "l1_im", "separation_db")   # BSRNN_M_* order
 
@@ -62,6 +62,8 @@ def _load():
         "bsrnn_dual_path": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp]),
         "bsrnn_lstm_train_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "bsrnn_lstm_train_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+        "bsrnn_linear_train_forward": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        "bsrnn_linear_train_backward": (C.c_int, [vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
         "bsrnn_stft": (C.c_int, [vp, vp, vp, i32, i64, vp]),
         "bsrnn_istft": (C.c_int, [vp, vp, vp, i32, i32, vp]),
         "bsrnn_separate": (C.c_int, [vp, vp, vp, i32, i64, vp]),

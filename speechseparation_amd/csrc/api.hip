@@ -1247,6 +1247,43 @@ int bsrnn_lstm_train_backward(bsrnn_ctx* c, const float* x, const float* h, cons
     return 0;
 }
 
+int bsrnn_linear_train_forward(bsrnn_ctx* c, const float* x, int32_t ldx, const float* w, const float* b, float* y, int32_t ldy,
+                               int32_t M, int32_t K, int32_t N, int32_t leaky, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    if (!x || !w || !b || !y || M < 1 || K < 1 || N < 1 || ldx < K || ldy < N)
+        return fail(BSRNN_EARG, "bsrnn_linear_train_forward: bad arguments (M=%d K=%d N=%d ldx=%d ldy=%d)", M, K, N, ldx, ldy);
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    launch_linear_train_forward(x, ldx, w, b, y, ldy, M, K, N, leaky != 0, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_linear_train_backward(bsrnn_ctx* c, const float* x, int32_t ldx, const float* w, const float* y, int32_t ldy,
+                                const float* dy, int32_t lddy, float* dx, int32_t lddx, float* dw, float* db,
+                                int32_t M, int32_t K, int32_t N, int32_t leaky, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    if (!x || !w || !dy || !dw || !db || (leaky && !y) || M < 1 || K < 1 || N < 1 || ldx < K || lddy < N || (leaky && ldy < N) || (dx && lddx < K))
+        return fail(BSRNN_EARG, "bsrnn_linear_train_backward: bad arguments (M=%d K=%d N=%d)", M, K, N);
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    const size_t n_scr = linear_train_scratch_floats(M, K, N, leaky != 0);
+    float* ws = nullptr;
+    if (hipMallocAsync((void**)&ws, n_scr * sizeof(float), s) != hipSuccess || !ws) {
+        (void)hipGetLastError();
+        return fail(BSRNN_EHIP, "bsrnn_linear_train_backward: out of device memory (%zu MB of workspace)", n_scr * sizeof(float) >> 20);
+    }
+    launch_linear_train_backward(x, ldx, w, y, ldy, dy, lddy, dx, lddx, dw, db, ws, M, K, N, leaky != 0, s);
+    const hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(ws, s);
+    if (e != hipSuccess) return fail(BSRNN_EHIP, "bsrnn_linear_train_backward: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // --------------------------------------------------------------------------- STFT sandwich
 int bsrnn_stft(bsrnn_ctx* c, const float* wave, float* x, int32_t R, int64_t n, void* stream)
 {

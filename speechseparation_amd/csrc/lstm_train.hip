@@ -208,125 +208,12 @@ __global__ __launch_bounds__(256, 2) void lstm_train_bwd_kernel(const float* __r
     }
 }
 
-// ---------------------------------------------------------------------------------------------- matrix products over all rows
-// C [M][N] (+)= A [M][K] B [K][N], row-major with leading dimensions (dx = dg W_ih).  64 x 64 tile per workgroup, wave w
-// the 16-row strip w, K in slabs of 16 through LDS.
-__global__ __launch_bounds__(256) void sgemm_nn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                       float* __restrict__ C, int ldc, int M, int N, int K, int accumulate)
-{
-    __shared__ float sa[64][17], sb[16][65];
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, q = lane >> 4;
-    v4f acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int ar = idx >> 4, ac = idx & 15;           // A slab: 64 rows x 16 k
-            const int m = m0 + ar, k = k0 + ac;
-            sa[ar][ac] = (m < M && k < K) ? A[(size_t)m * lda + k] : 0.f;
-            const int br = idx >> 6, bc = idx & 63;           // B slab: 16 k x 64 columns
-            const int kk = k0 + br, n = n0 + bc;
-            sb[br][bc] = (kk < K && n < N) ? B[(size_t)kk * ldb + n] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float a = sa[16 * wave + l15][4 * s + q];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[4 * s + q][16 * j + l15], acc[j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 16 * wave + 4 * q + r, n = n0 + 16 * j + l15;
-            if (m < M && n < N) {
-                float* p = C + (size_t)m * ldc + n;
-                *p = accumulate ? *p + acc[j][r] : acc[j][r];
-            }
-        }
-}
-
-// Partial sums of C [N1][N2] = A^T B over the row chunk blockIdx.z: A [M][N1] (lda), B [M][N2] (ldb), both row-major.
-// `shift`: B's row for A's row m = (n, t) is (n, t + shift), zero where t + shift leaves [0, L) (h_prev of dW_hh); 0: same row.
-// Partials [chunks][N1][N2] are summed by reduce_partials_kernel in a fixed order (deterministic gradients).
-__global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                               float* __restrict__ part, int M, int N1, int N2, int rows_per_chunk,
-                                                               int L, int shift)
-{
-    __shared__ float sa[16][65], sb[16][65];
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-    const int r_lo = blockIdx.z * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, q = lane >> 4;
-    v4f acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int m0 = r_lo; m0 < r_hi; m0 += 16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int rr = idx >> 6, cc = idx & 63;
-            const int m = m0 + rr;
-            sa[rr][cc] = (m < r_hi && i0 + cc < N1) ? A[(size_t)m * lda + i0 + cc] : 0.f;
-            float bv = 0.f;
-            if (m < r_hi && j0 + cc < N2) {
-                const int t = m % L + shift;
-                if (t >= 0 && t < L) bv = B[(size_t)(m + shift) * ldb + j0 + cc];
-            }
-            sb[rr][cc] = bv;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float a = sa[4 * s + q][16 * wave + l15];       // A^T: tile row = column of A
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[4 * s + q][16 * j + l15], acc[j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    float* out = part + (size_t)blockIdx.z * N1 * N2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + 16 * wave + 4 * q + r, jj = j0 + 16 * j + l15;
-            if (i < N1 && jj < N2) out[(size_t)i * N2 + jj] = acc[j][r];
-        }
-}
-
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int chunks)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
-    out[i] = s;
-}
-
-// column sums of dg [M][cols] over row chunks (bias gradients); partials [chunks][cols]
-__global__ void colsum_partial_kernel(const float* __restrict__ A, float* __restrict__ part, int M, int cols, int rows_per_chunk)
-{
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= cols) return;
-    const int r_lo = blockIdx.y * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
-    float s = 0.f;
-    for (int m = r_lo; m < r_hi; ++m) s += A[(size_t)m * cols + col];
-    part[(size_t)blockIdx.y * cols + col] = s;
-}
-
 }  // namespace
 
 size_t lstm_train_scratch_floats(int IN, int ndir)
 {
-    const size_t w = (size_t)256 * (IN > HID ? IN : HID), b = (size_t)ndir * 256;      // partial weight / bias gradients per chunk
-    return (size_t)LSTM_TRAIN_CHUNKS * (w > b ? w : b);
+    const size_t w = sgemm_tn_scratch_floats(256, IN > HID ? IN : HID), b = colsum_scratch_floats(ndir * 256);
+    return w > b ? w : b;
 }
 
 void launch_lstm_train_forward(const float* x, const float* w_ih, const float* w_hh, const float* bias, float* h, float* gates,
@@ -348,25 +235,15 @@ void launch_lstm_train_backward(const float* x, const float* h, const float* gat
     if (N <= 0 || L <= 0) return;
     const int M = N * L, HO = ndir * HID;
     hipLaunchKernelGGL(lstm_train_bwd_kernel, dim3((N + 15) / 16, ndir), dim3(256), 0, s, gates, cells, dh, w_hh, dg, N, L, ndir);
-    const int chunks = LSTM_TRAIN_CHUNKS;
-    const int rpc = ((M + chunks - 1) / chunks + 15) / 16 * 16;
     for (int d = 0; d < ndir; ++d) {
         const float* dgd = dg + (size_t)d * 256;                   // rows of 256 inside records of ndir 256
         const int ldg = ndir * 256;
-        if (dx)
-            hipLaunchKernelGGL(sgemm_nn_kernel, dim3((M + 63) / 64, (IN + 63) / 64), dim3(256), 0, s, dgd, ldg, w_ih + (size_t)d * 256 * IN, IN,
-                               dx, IN, M, IN, 256, d > 0);
-        // dW_ih = dg^T x
-        hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3(4, (IN + 63) / 64, chunks), dim3(256), 0, s, dgd, ldg, x, IN, scratch, M, 256, IN, rpc, L, 0);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((256 * IN + 255) / 256), dim3(256), 0, s, scratch, dw_ih + (size_t)d * 256 * IN, 256 * IN, chunks);
+        if (dx) launch_sgemm(dgd, ldg, w_ih + (size_t)d * 256 * IN, IN, 0, dx, IN, M, IN, 256, d > 0, nullptr, 0, s);
+        launch_sgemm_tn(dgd, ldg, x, IN, dw_ih + (size_t)d * 256 * IN, scratch, M, 256, IN, L, 0, s);          // dW_ih = dg^T x
         // dW_hh = dg^T h_prev: the forward pass of direction 0 read h_{t-1}, direction 1 h_{t+1}
-        hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3(4, 1, chunks), dim3(256), 0, s, dgd, ldg, h + (size_t)d * HID, HO, scratch, M, 256, HID, rpc, L,
-                           d ? 1 : -1);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((256 * HID + 255) / 256), dim3(256), 0, s, scratch, dw_hh + (size_t)d * 256 * HID, 256 * HID, chunks);
+        launch_sgemm_tn(dgd, ldg, h + (size_t)d * HID, HO, dw_hh + (size_t)d * 256 * HID, scratch, M, 256, HID, L, d ? 1 : -1, s);
     }
-    // db: column sums over all rows, all directions at once (columns = ndir 256)
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((ndir * 256 + 255) / 256, chunks), dim3(256), 0, s, dg, scratch, M, ndir * 256, rpc);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((ndir * 256 + 255) / 256), dim3(256), 0, s, scratch, db, ndir * 256, chunks);
+    launch_colsum(dg, ndir * 256, db, scratch, M, ndir * 256, s);      // db: all directions at once (columns = ndir 256)
 }
 
 }  // namespace bsrnn

@@ -1,0 +1,220 @@
+// Training step: the plain matrix products around the recurrent kernels (lstm_train.hip) and the per-band Linear layers
+// (nn.Linear + LeakyReLU of bandFCs_pre / bandFCs / bandFCs_back / bandFCs_back_post and the fc / fc_in of NormRNNResidual,
+// bsrnn.py:333-376, :69, :74) as forward and backward, i.e. what torch.autograd runs for them in train.py:97-115.
+// Exact fp32 on v_mfma_f32_16x16x4_f32; first, correct versions (64 x 64 tiles through LDS, one K slab per barrier pair),
+// not yet tuned: the inference path's grouped / fused kernels are the model for the next pass.
+//   forward   y = act(x W^T + b)                                   x [M][K], W [N][K] (torch layout), y [M][N]
+//   backward  dp = dy * act'(y);  dx = dp W;  dW = dp^T x;  db = column sums of dp
+// Weight-gradient reductions over the M rows run in LSTM_TRAIN_CHUNKS fixed chunks that are then added in order:
+// gradients are bit-reproducible (no atomics).
+#include "kernels.h"
+
+namespace bsrnn {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// C [M][N] (+)= A [M][K] op(B) (+ bias[N]) (LeakyReLU), op(B) = B [K][N] or (TRANS_B) B^T with B [N][K]; row-major with
+// leading dimensions.  64 x 64 tile per workgroup, wave w the 16-row strip w, K in slabs of 16 through LDS.
+template <bool TRANS_B>
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                    float* __restrict__ C, int ldc, int M, int N, int K, int accumulate,
+                                                    const float* __restrict__ bias, int leaky)
+{
+    __shared__ float sa[64][17], sb[16][65];
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    v4f acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int ar = idx >> 4, ac = idx & 15;           // A slab: 64 rows x 16 k
+            const int m = m0 + ar, k = k0 + ac;
+            sa[ar][ac] = (m < M && k < K) ? A[(size_t)m * lda + k] : 0.f;
+            if (TRANS_B) {                                    // B^T slab from B [N][K]: k contiguous
+                const int bn = idx >> 4, bk = idx & 15;
+                const int n = n0 + bn, kk = k0 + bk;
+                sb[bk][bn] = (n < N && kk < K) ? B[(size_t)n * ldb + kk] : 0.f;
+            } else {                                          // B slab: 16 k x 64 columns
+                const int br = idx >> 6, bc = idx & 63;
+                const int kk = k0 + br, n = n0 + bc;
+                sb[br][bc] = (kk < K && n < N) ? B[(size_t)kk * ldb + n] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a = sa[16 * wave + l15][4 * s + q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[4 * s + q][16 * j + l15], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * q + r, n = n0 + 16 * j + l15;
+            if (m < M && n < N) {
+                float* p = C + (size_t)m * ldc + n;
+                float v = acc[j][r];
+                if (bias) v += bias[n];
+                if (accumulate) v += *p;
+                if (leaky) v = v >= 0.f ? v : 0.01f * v;
+                *p = v;
+            }
+        }
+}
+
+// Partial sums of C [N1][N2] = A^T B over the row chunk blockIdx.z: A [M][N1] (lda), B [M][N2] (ldb), both row-major.
+// `shift`: B's row for A's row m = (n, t) is (n, t + shift), zero where t + shift leaves [0, L) (h_prev of dW_hh); 0: same row.
+__global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                               float* __restrict__ part, int M, int N1, int N2, int rows_per_chunk,
+                                                               int L, int shift)
+{
+    __shared__ float sa[16][65], sb[16][65];
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int r_lo = blockIdx.z * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    v4f acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int m0 = r_lo; m0 < r_hi; m0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int rr = idx >> 6, cc = idx & 63;
+            const int m = m0 + rr;
+            sa[rr][cc] = (m < r_hi && i0 + cc < N1) ? A[(size_t)m * lda + i0 + cc] : 0.f;
+            float bv = 0.f;
+            if (m < r_hi && j0 + cc < N2) {
+                const int t = m % L + shift;
+                if (t >= 0 && t < L) bv = B[(size_t)(m + shift) * ldb + j0 + cc];
+            }
+            sb[rr][cc] = bv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a = sa[4 * s + q][16 * wave + l15];       // A^T: tile row = column of A
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[4 * s + q][16 * j + l15], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* out = part + (size_t)blockIdx.z * N1 * N2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 16 * wave + 4 * q + r, jj = j0 + 16 * j + l15;
+            if (i < N1 && jj < N2) out[(size_t)i * N2 + jj] = acc[j][r];
+        }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int chunks)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
+    out[i] = s;
+}
+
+// column sums of A [M][cols] (lda) over row chunks (bias gradients); partials [chunks][cols]
+__global__ void colsum_partial_kernel(const float* __restrict__ A, int lda, float* __restrict__ part, int M, int cols, int rows_per_chunk)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    const int r_lo = blockIdx.y * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
+    float s = 0.f;
+    for (int m = r_lo; m < r_hi; ++m) s += A[(size_t)m * lda + col];
+    part[(size_t)blockIdx.y * cols + col] = s;
+}
+
+// dp = dy * (y >= 0 ? 1 : 0.01): the derivative of LeakyReLU(0.01) read off its output (0.01 > 0 keeps the sign)
+__global__ void leaky_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, float* __restrict__ dp,
+                                 int M, int N)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    const float g = dy[(size_t)m * lddy + n];
+    dp[i] = y[(size_t)m * ldy + n] >= 0.f ? g : 0.01f * g;
+}
+
+int rows_per_chunk(int M)
+{
+    return ((M + LSTM_TRAIN_CHUNKS - 1) / LSTM_TRAIN_CHUNKS + 15) / 16 * 16;
+}
+
+}  // namespace
+
+size_t sgemm_tn_scratch_floats(int N1, int N2) { return (size_t)LSTM_TRAIN_CHUNKS * N1 * N2; }
+size_t colsum_scratch_floats(int cols) { return (size_t)LSTM_TRAIN_CHUNKS * cols; }
+
+void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, int M, int N, int K,
+                  int accumulate, const float* bias, int leaky, hipStream_t s)
+{
+    if (M <= 0 || N <= 0) return;
+    const dim3 grid((M + 63) / 64, (N + 63) / 64), block(256);
+    if (trans_b) hipLaunchKernelGGL(sgemm_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, bias, leaky);
+    else hipLaunchKernelGGL(sgemm_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, bias, leaky);
+}
+
+void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* out, float* scratch, int M, int N1, int N2, int L,
+                     int shift, hipStream_t s)
+{
+    if (N1 <= 0 || N2 <= 0) return;
+    const int rpc = rows_per_chunk(M);
+    hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3((N1 + 63) / 64, (N2 + 63) / 64, LSTM_TRAIN_CHUNKS), dim3(256), 0, s, A, lda, B, ldb, scratch,
+                       M, N1, N2, rpc, L > 0 ? L : 1, shift);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N1 * N2 + 255) / 256), dim3(256), 0, s, scratch, out, N1 * N2, LSTM_TRAIN_CHUNKS);
+}
+
+void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, int cols, hipStream_t s)
+{
+    if (cols <= 0) return;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, LSTM_TRAIN_CHUNKS), dim3(256), 0, s, A, lda, scratch, M, cols, rows_per_chunk(M));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols, LSTM_TRAIN_CHUNKS);
+}
+
+// ---------------------------------------------------------------------------------------------- nn.Linear (+ LeakyReLU)
+void launch_linear_train_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
+                                 int leaky, hipStream_t s)
+{
+    launch_sgemm(x, ldx, w, K, 1, y, ldy, M, N, K, 0, b, leaky, s);
+}
+
+size_t linear_train_scratch_floats(int M, int K, int N, int leaky)
+{
+    const size_t r = sgemm_tn_scratch_floats(N, K), c = colsum_scratch_floats(N);
+    return (r > c ? r : c) + (leaky ? (size_t)M * N : 0);
+}
+
+// dx may be null; y is only read when leaky.  scratch: linear_train_scratch_floats.
+void launch_linear_train_backward(const float* x, int ldx, const float* w, const float* y, int ldy, const float* dy, int lddy,
+                                  float* dx, int lddx, float* dw, float* db, float* scratch, int M, int K, int N, int leaky,
+                                  hipStream_t s)
+{
+    if (M <= 0 || N <= 0) return;
+    const float* dp = dy;
+    int lddp = lddy;
+    if (leaky) {
+        const size_t r = sgemm_tn_scratch_floats(N, K), c = colsum_scratch_floats(N);
+        float* buf = scratch + (r > c ? r : c);
+        hipLaunchKernelGGL(leaky_bwd_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, dy, lddy, y, ldy, buf, M, N);
+        dp = buf; lddp = N;
+    }
+    if (dx && K > 0) launch_sgemm(dp, lddp, w, K, 0, dx, lddx, M, K, N, 0, nullptr, 0, s);       // dx = dp W
+    if (K > 0) launch_sgemm_tn(dp, lddp, x, ldx, dw, scratch, M, N, K, 1, 0, s);                  // dW = dp^T x
+    launch_colsum(dp, lddp, db, scratch, M, N, s);
+}
+
+}  // namespace bsrnn

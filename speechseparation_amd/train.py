@@ -98,3 +98,98 @@ def stack_direction_weights(lstm, layer):
     sfx = ["", "_reverse"][: 2 if lstm.bidirectional else 1]
     get = lambda name: torch.stack([getattr(lstm, "%s_l%d%s" % (name, layer, s)) for s in sfx])   # noqa: E731
     return get("weight_ih"), get("weight_hh"), get("bias_ih"), get("bias_hh")
+
+
+# ------------------------------------------------------------------------------------------ nn.Linear (+ LeakyReLU)
+def _rows(t):
+    """2-D view whose rows are contiguous (a band is a column block of wider rows: row stride = the leading dimension)."""
+    return t if (t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32) else t.to(torch.float32).contiguous()
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = act(x W^T + b) on [M, K] rows with the library's forward and backward (bsrnn_linear_train_*);
+    apply(x, weight, bias, leaky) where leaky selects LeakyReLU(0.01) (nn.LeakyReLU() of the reference's Sequentials)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, leaky):
+        if not x.is_cuda:
+            raise ValueError("the training kernels run on the GPU: x must be a cuda tensor")
+        x, w, b = _rows(x.detach()), _f32c(w), _f32c(b)
+        M, K = x.shape
+        N = w.shape[0]
+        if tuple(w.shape) != (N, K) or tuple(b.shape) != (N,):
+            raise ValueError("Linear: weight %s / bias %s do not match x [M, %d]" % (tuple(w.shape), tuple(b.shape), K))
+        dev = x.device
+        with torch.cuda.device(dev):
+            y = torch.empty((M, N), device=dev)
+            _native.check(_lib.bsrnn_linear_train_forward(_context(dev), _p(x), x.stride(0), _p(w), _p(b), _p(y), N, M, K, N, int(leaky), _s(dev)))
+        ctx.save_for_backward(x, w, y)
+        ctx.leaky = bool(leaky)
+        ctx.need_dx = True
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[0]
+        dy = _rows(dy)
+        dev = x.device
+        with torch.cuda.device(dev):
+            dx = torch.empty((M, K), device=dev) if ctx.needs_input_grad[0] else None
+            dw, db = torch.empty_like(w), torch.empty((N,), device=dev)
+            _native.check(_lib.bsrnn_linear_train_backward(_context(dev), _p(x), x.stride(0), _p(w), _p(y), N, _p(dy), dy.stride(0), _p(dx), K,
+                                                           _p(dw), _p(db), M, K, N, int(ctx.leaky), _s(dev)))
+        return dx, dw, db, None
+
+
+def _linear(x, lin, leaky):
+    return LinearFunction.apply(x, lin.weight, lin.bias, leaky)
+
+
+def _rnn_block(m, x):
+    """NormRNNResidual (bsrnn.py:78-87) on [N, L, 64]: fc_in -> 2-layer LSTM -> fc -> + x."""
+    N, L, H = x.shape
+    u = _linear(x.reshape(N * L, H), m.fc_in, False).reshape(N, L, H)
+    for layer in range(m.rnn.num_layers):
+        u = LstmLayerFunction.apply(u, *stack_direction_weights(m.rnn, layer))
+    return _linear(u.reshape(N * L, u.shape[2]), m.fc, False).reshape(N, L, H) + x
+
+
+def forward_train(model, x):
+    """BSRNN.forward (bsrnn.py:385-443) with the autograd graph kept: every parameterised layer (the 110 Linear layers of the
+    band MLPs, fc_in / fc and the LSTM layers of the four dual-path blocks) runs the library's training kernels forward and
+    backward; the glue without parameters (slices, stack, permutes, residual adds, x * mask) is torch on the same device.
+    `model` is a speechseparation_amd.BSRNN on a cuda device; x [C, 2050, T] -> y [C, 2050, T]."""
+    C, F2, T = x.shape
+    v = model.band_widths
+    H = band_features
+    xt = x.permute(0, 2, 1).reshape(C * T, F2)                    # frame rows (bsrnn.py:406)
+    residual, feats, pos = [], [], 0
+    for i, w in enumerate(v):
+        if w == 0:                                              # TrainableConstantModule (bsrnn.py:12-24)
+            residual.append(None)
+            feats.append(model.bandFCs[i][0].trainable_constant.expand(C * T, H))
+            continue
+        pre, fc = model.bandFCs_pre[i], model.bandFCs[i]
+        y = _linear(_linear(xt[:, pos:pos + 2 * w], pre[0], True), pre[2], True)
+        pos += 2 * w
+        residual.append(y)
+        feats.append(_linear(_linear(_linear(y, fc[0], True), fc[2], True), fc[4], False))
+    K = len(v)
+    z = torch.stack(feats, 1).reshape(C, T, K, H)               # bsrnn.py:415
+    for j, holder in enumerate(model.lstms):
+        if j % 2 == 0:                                          # BandwiseLSTM (bsrnn.py:138-153)
+            z = _rnn_block(holder.m, z.reshape(C * T, K, H)).reshape(C, T, K, H)
+        else:                                                   # TimewiseLSTM (bsrnn.py:106-120)
+            zt = z.permute(0, 2, 1, 3).reshape(C * K, T, H)
+            z = _rnn_block(holder.m, zt).reshape(C, K, T, H).permute(0, 2, 1, 3)
+    parts = []
+    for i, w in enumerate(v):
+        if w == 0:
+            continue
+        back, post = model.bandFCs_back[i], model.bandFCs_back_post[i]
+        b = _linear(_linear(_linear(z[:, :, i, :].reshape(C * T, H), back[0], True), back[2], True), back[4], True)
+        parts.append(residual[i] + _linear(_linear(b, post[0], True), post[2], False))
+    mask = torch.cat(parts, 1).reshape(C, T, F2).permute(0, 2, 1)  # bsrnn.py:430-432
+    return x * mask

@@ -94,3 +94,65 @@ def test_backward_is_bit_reproducible_and_validates_arguments():
         train.lstm_layer_forward(torch.randn(4, 3, 96, device="cuda"), torch.randn(1, 256, 96, device="cuda"), w_hh[:1], b[:1])
     with pytest.raises(ValueError):
         train.lstm_layer_forward(x.cpu(), w_ih, w_hh, b)
+
+
+@pytest.mark.parametrize("M,K,N,leaky", [(200, 2, 2, True), (777, 96, 64, True), (1000, 768, 768, True), (130, 64, 128, False), (64, 514, 514, False)])
+def test_linear_forward_and_backward_match_autograd(M, K, N, leaky):
+    """nn.Linear (+ LeakyReLU) of the band MLPs on a column block of wider rows, against torch on the CPU."""
+    from speechseparation_amd import train
+    torch.manual_seed(M + K)
+    wide = torch.randn(M, K + 13)
+    x = wide[:, 5:5 + K].clone().requires_grad_(True)
+    lin = torch.nn.Linear(K, N)
+    dy = torch.randn(M, N)
+    y_ref = lin(x)
+    if leaky:
+        y_ref = torch.nn.functional.leaky_relu(y_ref)
+    (y_ref * dy).sum().backward()
+
+    wg = wide.cuda()
+    xg = wg[:, 5:5 + K].requires_grad_(True)            # row stride K + 13
+    w, b = lin.weight.detach().cuda().requires_grad_(True), lin.bias.detach().cuda().requires_grad_(True)
+    y = train.LinearFunction.apply(xg, w, b, leaky)
+    (y * dy.cuda()).sum().backward()
+    assert _rel(y, y_ref) < 2e-6
+    errs = {"dx": _rel(xg.grad, x.grad), "dw": _rel(w.grad, lin.weight.grad), "db": _rel(b.grad, lin.bias.grad)}
+    print("M=%d K=%d N=%d leaky=%s: relative gradient errors %s" % (M, K, N, leaky, {k: "%.1e" % v for k, v in errs.items()}))
+    assert max(errs.values()) < 1e-4, errs
+
+
+def test_training_forward_and_backward_of_the_whole_model_match_autograd():
+    """forward_train = BSRNN.forward with every parameterised layer on the library's training kernels: the output and the
+    gradient of an L1 loss (m_dataset.py:211-216 uses L1 terms) w.r.t. all 288 parameter tensors against torch.autograd on
+    the CPU restatement of the reference (oracle/bsrnn_torch_cpu.py), C = 2 rows x T = 8 frames, the 'hot' weight set."""
+    from oracle.bsrnn_torch_cpu import TorchCpuBSRNN
+    from speechseparation_amd import spec, train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    v = spec.generate_bandsplits()[0]
+    sd = weights.synth_state_dict(None, seed=1, lstm_gain=3.0)
+    x = torch.from_numpy(weights.synth_tensor((2, 2050, 8), seed=5, scale=1.0))
+    target = torch.from_numpy(weights.synth_tensor((2, 2050, 8), seed=6, scale=1.0))
+
+    ref = TorchCpuBSRNN(sd, v)
+    params = ref.trainable()
+    y_ref = ref.forward_differentiable(x)
+    (y_ref - target).abs().mean().backward()
+
+    m = BSRNN().train()
+    m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+    m = m.to("cuda:0")
+    y = train.forward_train(m, x.cuda())
+    (y - target.cuda()).abs().mean().backward()
+    assert float((y.detach().cpu() - y_ref.detach()).abs().max()) < 1e-4
+    worst = ("", 0.0)
+    n = 0
+    for name, p in m.named_parameters():
+        g_ref = params[name].grad
+        if p.numel() == 0:
+            continue
+        assert p.grad is not None and g_ref is not None, name
+        e = _rel(p.grad, g_ref) if float(g_ref.abs().max()) > 0 else float(p.grad.abs().max())
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        n += 1
+    print("%d parameter tensors, worst relative gradient error %.2e (%s)" % (n, worst[1], worst[0]))
+    assert n >= 280 and worst[1] < 1e-3, worst
