@@ -173,6 +173,11 @@ int  bsrnn_linear_train_backward(bsrnn_ctx* ctx, const float* x_dev, int32_t ldx
                                  int32_t ldy, const float* dy_dev, int32_t lddy, float* dx_dev, int32_t lddx,
                                  float* dw_dev, float* db_dev, int32_t M, int32_t K, int32_t N, int32_t leaky, void* stream);
 
+/* torch.optim.AdamW(model.parameters(), lr, weight_decay) of train.py:50, one tensor per call: p, m (exp_avg), v (exp_avg_sq)
+ * updated in place from the gradient g; `step` counts from 1 (bias correction).  n floats each, device pointers. */
+int  bsrnn_adamw_step(bsrnn_ctx* ctx, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
 /* ---- the STFT sandwich of the callers --------------------------------------------------
  * bsrnn_stft   = infer.py:29-33 (dup. m_dataset.py:187-190): wave_dev [R, n] ->
  *                x_dev [R, 2050, T], T = 1 + n/1024; periodic Hann 2048, hop 1024,
@@ -182,6 +187,11 @@ int  bsrnn_linear_train_backward(bsrnn_ctx* ctx, const float* x_dev, int32_t ldx
  *                [C,2050,T] round trips): wave_dev [R, n] -> wave_out_dev [R, (T-1)*1024]. */
 int  bsrnn_stft(bsrnn_ctx* ctx, const float* wave_dev, float* x_dev, int32_t R, int64_t n, void* stream);
 int  bsrnn_istft(bsrnn_ctx* ctx, const float* y_dev, float* wave_out_dev, int32_t R, int32_t T, void* stream);
+/* Backward of bsrnn_istft for the training step (the loss of m_dataset.py:211-216 has a waveform term): dwave_dev
+ * [R, (T-1)*1024] = gradient w.r.t. the waveform -> dy_dev [R, 2050, T] = gradient w.r.t. the spectrum (the transpose of
+ * torch.istft: zero-padded windowed FFT of dwave / envelope, one-sided bins weighted 1, 2, ..., 2, 1 over 2048, no gradient
+ * for the imaginary parts of bins 0 and 1024). */
+int  bsrnn_istft_backward(bsrnn_ctx* ctx, const float* dwave_dev, float* dy_dev, int32_t R, int32_t T, void* stream);
 int  bsrnn_separate(bsrnn_ctx* ctx, const float* wave_dev, float* wave_out_dev, int32_t R, int64_t n, void* stream);
 
 /* ---- validation metrics (m_dataset.py:182-226 `infer` + `train_infer`, infer.py:44-47) ------

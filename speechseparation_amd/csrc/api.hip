@@ -1247,6 +1247,21 @@ int bsrnn_lstm_train_backward(bsrnn_ctx* c, const float* x, const float* h, cons
     return 0;
 }
 
+int bsrnn_adamw_step(bsrnn_ctx* c, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int32_t step, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    if (!p || !g || !m || !v || n < 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
+        return fail(BSRNN_EARG, "bsrnn_adamw_step: bad arguments (n=%lld step=%d)", (long long)n, step);
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    launch_adamw(p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int bsrnn_linear_train_forward(bsrnn_ctx* c, const float* x, int32_t ldx, const float* w, const float* b, float* y, int32_t ldy,
                                int32_t M, int32_t K, int32_t N, int32_t leaky, void* stream)
 {
@@ -1318,6 +1333,30 @@ int bsrnn_istft(bsrnn_ctx* c, const float* y, float* wave_out, int32_t R, int32_
         launch_istft(c->tb, c->Yf, wave_out, R, T, s);
     }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_istft_backward(bsrnn_ctx* c, const float* dwave, float* dy, int32_t R, int32_t T, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!dwave || !dy || R < 1 || T < 2) return fail(BSRNN_EARG, "bsrnn_istft_backward: need T >= 2 frames");
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    int rc = ensure_ws(c, (size_t)R * T);
+    if (rc) return rc;
+    float* ws = nullptr;
+    const size_t n_g = (size_t)R * (T - 1) * HOPS;
+    if (hipMallocAsync((void**)&ws, n_g * sizeof(float), s) != hipSuccess || !ws) {
+        (void)hipGetLastError();
+        return fail(BSRNN_EHIP, "bsrnn_istft_backward: out of device memory");
+    }
+    launch_istft_backward(c->tb, dwave, ws, c->Yf, R, T, s);
+    launch_from_frame_major(c->tb, c->Yf, dy, R, T, s);
+    const hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(ws, s);
+    if (e != hipSuccess) return fail(BSRNN_EHIP, "bsrnn_istft_backward: %s", hipGetErrorString(e));
     return 0;
 }
 

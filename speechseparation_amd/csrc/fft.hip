@@ -185,6 +185,7 @@ static int frames_per_workgroup(int units, int rows, int slots, int extra)
 // One workgroup transforms `sch` consecutive frames of one row.  Frames overlap by half: the thread that owns complex
 // samples c + 512, c + 768 of frame t owns c, c + 256 of frame t + 1, so only the new half is loaded per frame
 // (requested before the FFT passes of the current frame) and the raw samples stay in registers.
+template <bool ZERO_PAD>      // ZERO_PAD: samples outside [0, n) are zeros instead of reflections (the adjoint of the iSTFT, below)
 __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __restrict__ wave, float* __restrict__ X,
                                                    int64_t n, int T, int sch)
 {
@@ -205,6 +206,10 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             int64_t idx = (int64_t)t * HOPS + 2 * c + e - NFFT / 2;
+            if (ZERO_PAD) {
+                v[e] = (idx >= 0 && idx < n) ? src[idx] : 0.f;
+                continue;
+            }
             if (idx < 0) idx = -idx;
             if (idx >= n) idx = 2 * (n - 1) - idx;
             v[e] = src[idx];
@@ -228,10 +233,49 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
 
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s)
 {
-    static const int slots = resident_slots((const void*)stft_kernel);
+    static const int slots = resident_slots((const void*)stft_kernel<false>);
     const int sch = frames_per_workgroup(T, R, slots, 0);
     dim3 grid((unsigned)((T + sch - 1) / sch), R);
-    hipLaunchKernelGGL(stft_kernel, grid, dim3(256), 0, s, tb, wave, X, n, T, sch);
+    hipLaunchKernelGGL(stft_kernel<false>, grid, dim3(256), 0, s, tb, wave, X, n, T, sch);
+}
+
+// ------------------------------------------------------------------------------ backward of the offline iSTFT (training step)
+// torch.istft (infer.py:35-37 / m_dataset.py:192-195) is linear in the spectrum: wave[n] = (1 / env[n]) sum_t w[j] irfft(Y_t)[j],
+// j = n + 1024 - 1024 t, env = sum of squared windows (two frames cover every kept sample).  Its transpose, applied to the
+// loss gradient g of the waveform, is an STFT of g / env with ZERO padding (the trimmed ends carry no gradient) whose bins
+// are scaled by c_k / 2048, c_0 = c_1024 = 1, else 2 (a one-sided bin stands for itself and its mirror), and the imaginary
+// parts of bins 0 and 1024 (which irfft ignores) get no gradient.  dwave [R][(T-1) 1024] -> dY frame-major [R T][ld].
+__global__ void istft_bwd_prescale_kernel(FftTables tb, const float* __restrict__ dwave, float* __restrict__ g, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % HOPS);                       // rows are multiples of 1024 long
+    const float w0 = tb.hann[j], w1 = tb.hann[j + HOPS];
+    g[i] = dwave[i] / (w0 * w0 + w1 * w1);
+}
+__global__ void istft_bwd_postscale_kernel(FftTables tb, float* __restrict__ X, size_t rows)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * NBINS) return;
+    const size_t row = i / NBINS;
+    const int k = (int)(i % NBINS);
+    float* p = X + row * tb.ld + tb.colmap[k];
+    const bool edge = k == 0 || k == NBINS - 1;
+    const float sc = (edge ? 1.0f : 2.0f) / (float)NFFT;
+    p[0] *= sc;
+    p[1] = edge ? 0.f : p[1] * sc;
+}
+void launch_istft_backward(const FftTables& tb, const float* dwave, float* scratch, float* dY, int R, int T, hipStream_t s)
+{
+    if (T < 2) return;
+    const int64_t n = (int64_t)(T - 1) * HOPS;
+    const size_t total = (size_t)R * n;
+    hipLaunchKernelGGL(istft_bwd_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tb, dwave, scratch, total);
+    static const int slots = resident_slots((const void*)stft_kernel<true>);
+    const int sch = frames_per_workgroup(T, R, slots, 0);
+    hipLaunchKernelGGL(stft_kernel<true>, dim3((unsigned)((T + sch - 1) / sch), R), dim3(256), 0, s, tb, scratch, dY, n, T, sch);
+    const size_t rows = (size_t)R * T;
+    hipLaunchKernelGGL(istft_bwd_postscale_kernel, dim3((unsigned)((rows * NBINS + 255) / 256)), dim3(256), 0, s, tb, dY, rows);
 }
 
 // ------------------------------------------------------------------------------ offline iSTFT

@@ -146,6 +146,9 @@ void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b,
 void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* out, float* scratch, int M, int N1, int N2, int L,
                      int shift, hipStream_t stream);
 void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, int cols, hipStream_t stream);
+// one AdamW update of n parameters (torch.optim.AdamW semantics; bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t))
+void launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                  float bc1, float bc2s, hipStream_t stream);
 // nn.Linear (+ LeakyReLU(0.01)): y = act(x W^T + b), W [N][K]; backward: dx (may be null), dW, db from dy (and y when leaky)
 size_t linear_train_scratch_floats(int M, int K, int N, int leaky);
 void launch_linear_train_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
@@ -176,6 +179,9 @@ struct FftTables {           // device tables, built once per context (double pr
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s);
 // Y frame-major [R*T][ld] -> wave_out [R][(T-1)*1024]: inverse real FFT, synthesis window, overlap-add / envelope, fused
 void launch_istft(const FftTables& tb, const float* Y, float* out, int R, int T, hipStream_t s);
+// gradient of launch_istft's output w.r.t. its input (training step): dwave [R][(T-1)*1024] -> dY frame-major [R*T][ld];
+// scratch [R][(T-1)*1024]
+void launch_istft_backward(const FftTables& tb, const float* dwave, float* scratch, float* dY, int R, int T, hipStream_t s);
 // [C][2050][T] (reference layout) <-> [C*T][ld] (band-padded)
 void launch_to_frame_major(const FftTables& tb, const float* x, float* xf, int C, int T, hipStream_t s);
 void launch_from_frame_major(const FftTables& tb, const float* yf, float* y, int C, int T, hipStream_t s);

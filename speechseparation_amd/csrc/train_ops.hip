@@ -185,6 +185,29 @@ void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, i
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols, LSTM_TRAIN_CHUNKS);
 }
 
+// ---------------------------------------------------------------------------------------------- AdamW (train.py:50)
+// torch.optim.AdamW(lr, betas, eps, weight_decay) in torch's own operation order (decoupled decay first, then
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)); bc1 = 1 - b1^t and bc2s = sqrt(1 - b2^t) come from the host.
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);           // lerp, as torch: exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    const float denom = __builtin_sqrtf(vi) / bc2s + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+void launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                  float bc1, float bc2s, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s);
+}
+
 // ---------------------------------------------------------------------------------------------- nn.Linear (+ LeakyReLU)
 void launch_linear_train_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
                                  int leaky, hipStream_t s)

@@ -193,3 +193,93 @@ def forward_train(model, x):
         parts.append(residual[i] + _linear(_linear(b, post[0], True), post[2], False))
     mask = torch.cat(parts, 1).reshape(C, T, F2).permute(0, 2, 1)  # bsrnn.py:430-432
     return x * mask
+
+
+# ------------------------------------------------------------------------------------------ the DSP ends and the loss
+def stft(wave):
+    """infer.py:29-33 / m_dataset.py:187-190 on the library's kernel: wave [R, n] (cuda) -> [R, 2050, 1 + n // 1024]; no gradient
+    (the mixture and the target are data)."""
+    R, n = wave.shape
+    dev = wave.device
+    w = _f32c(wave)
+    with torch.cuda.device(dev):
+        x = torch.empty((R, 2050, 1 + n // 1024), device=dev)
+        _native.check(_lib.bsrnn_stft(_context(dev), _p(w), _p(x), R, n, _s(dev)))
+    return x
+
+
+class IstftFunction(torch.autograd.Function):
+    """torch.istft of m_dataset.py:192-195 ([R, 2050, T] interleaved -> [R, (T-1)*1024]) with the library's kernel forward and
+    its transpose (bsrnn_istft_backward) backward."""
+
+    @staticmethod
+    def forward(ctx, y):
+        R, F2, T = y.shape
+        dev = y.device
+        yc = _f32c(y)
+        with torch.cuda.device(dev):
+            out = torch.empty((R, (T - 1) * 1024), device=dev)
+            _native.check(_lib.bsrnn_istft(_context(dev), _p(yc), _p(out), R, T, _s(dev)))
+        ctx.shape = (R, F2, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, dwave):
+        R, F2, T = ctx.shape
+        dev = dwave.device
+        g = _f32c(dwave)
+        with torch.cuda.device(dev):
+            dy = torch.empty((R, F2, T), device=dev)
+            _native.check(_lib.bsrnn_istft_backward(_context(dev), _p(g), _p(dy), R, T, _s(dev)))
+        return dy
+
+
+def train_loss(model, mix, speech):
+    """`train_infer` of the reference without the discriminator (m_dataset.py:182-216): STFT -> model -> iSTFT and the L1
+    tri-loss  L1(x_time, speech_time) + L1(Re X, Re S) + L1(Im X, Im S)  (nn.L1Loss, mean).  mix, speech [R, n] on the GPU.
+    Returns (loss, x_time); loss.backward() runs the library's backward kernels for every parameterised layer and the iSTFT."""
+    x = stft(mix)
+    y = forward_train(model, x)
+    x_time = IstftFunction.apply(y)
+    s = stft(speech)
+    s_time = speech[:, :x_time.shape[1]]
+    l1 = lambda a, b: (a - b).abs().mean()                      # noqa: E731
+    loss = l1(x_time, s_time) + l1(y[:, 0::2, :], s[:, 0::2, :]) + l1(y[:, 1::2, :], s[:, 1::2, :])
+    return loss, x_time
+
+
+# ------------------------------------------------------------------------------------------ optimizer and the step
+class AdamW:
+    """torch.optim.AdamW(params, lr=0.001, weight_decay=0.01) of train.py:50 on the library's kernel (one launch per tensor)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params if p.numel() > 0]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is None:
+                continue
+            g = _f32c(p.grad)
+            dev = p.device
+            with torch.cuda.device(dev):
+                _native.check(_lib.bsrnn_adamw_step(_context(dev), _p(p), _p(g), _p(m), _p(v), p.numel(), self.lr, self.betas[0], self.betas[1],
+                                                    self.eps, self.weight_decay, self.t, _s(dev)))
+
+
+def train_step(model, optimizer, mix, speech):
+    """One iteration of the reference's loop (train.py:97-115 with batch_size 1): loss, backward, optimizer step, zero_grad."""
+    loss, _ = train_loss(model, mix, speech)
+    loss.backward()
+    optimizer.step()
+    optimizer.zero_grad()
+    return loss.detach()

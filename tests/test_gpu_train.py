@@ -156,3 +156,116 @@ def test_training_forward_and_backward_of_the_whole_model_match_autograd():
         n += 1
     print("%d parameter tensors, worst relative gradient error %.2e (%s)" % (n, worst[1], worst[0]))
     assert n >= 280 and worst[1] < 1e-3, worst
+
+
+def test_istft_backward_is_the_transpose_of_torch_istft():
+    from speechseparation_amd import train
+    torch.manual_seed(3)
+    R, T = 3, 7
+    y = torch.randn(R, 2050, T, requires_grad=True)
+    g = torch.randn(R, (T - 1) * 1024)
+    yc = y.reshape(R, 1025, 2, T)
+    w = torch.istft(torch.complex(yc[:, :, 0, :], yc[:, :, 1, :]), n_fft=2048, hop_length=1024, window=torch.hann_window(2048))
+    (w * g).sum().backward()
+    yg = y.detach().cuda().requires_grad_(True)
+    wg = train.IstftFunction.apply(yg)
+    (wg * g.cuda()).sum().backward()
+    assert _rel(wg, w) < 2e-6
+    # torch gives the imaginary parts of bins 0 and 1024 no gradient either (irfft ignores them)
+    assert float(y.grad[:, 1, :].abs().max()) == 0.0 and float(yg.grad[:, 1, :].abs().max()) == 0.0
+    print("iSTFT backward: relative error %.1e" % _rel(yg.grad, y.grad))
+    assert _rel(yg.grad, y.grad) < 1e-5
+
+
+def test_train_loss_and_its_gradient_match_the_reference_train_step():
+    """m_dataset.train_infer (without discriminator) end to end: STFT -> BSRNN -> iSTFT -> L1 tri-loss and loss.backward(),
+    library kernels on the GPU against torch on the CPU (torch.stft / istft + the CPU restatement of the model)."""
+    from oracle.bsrnn_torch_cpu import TorchCpuBSRNN
+    from speechseparation_amd import spec, train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    v = spec.generate_bandsplits()[0]
+    sd = weights.synth_state_dict(None, seed=0)
+    mix = torch.from_numpy(weights.synth_waveform(2, 8 * 1024, seed=11))
+    speech = torch.from_numpy(weights.synth_waveform(2, 8 * 1024, seed=12))
+
+    ref = TorchCpuBSRNN(sd, v)
+    params = ref.trainable()
+    win = torch.hann_window(2048)
+
+    def spec_of(wv):
+        X = torch.stft(wv, n_fft=2048, hop_length=1024, return_complex=True, window=win)
+        return X
+
+    X = spec_of(mix)
+    x = torch.stack((X.real, X.imag), dim=2).reshape(2, 2050, -1)
+    y = ref.forward_differentiable(x)
+    yc = y.reshape(2, -1, 2, y.shape[2])
+    Y = torch.complex(yc[:, :, 0, :], yc[:, :, 1, :])
+    x_time = torch.istft(Y, n_fft=2048, hop_length=1024, window=win)
+    S = spec_of(speech)
+    l1 = torch.nn.L1Loss(reduction="mean")
+    loss_ref = l1(x_time, speech[:, :x_time.shape[1]]) + l1(Y.real, S.real) + l1(Y.imag, S.imag)
+    loss_ref.backward()
+
+    m = BSRNN().train()
+    m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+    m = m.to("cuda:0")
+    loss, xt = train.train_loss(m, mix.cuda(), speech.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    assert _rel(xt, x_time) < 1e-5
+    worst = ("", 0.0)
+    for name, p in m.named_parameters():
+        if p.numel() == 0:
+            continue
+        g_ref = params[name].grad
+        e = _rel(p.grad, g_ref) if float(g_ref.abs().max()) > 0 else float(p.grad.abs().max())
+        worst = max(worst, (name, e), key=lambda t: t[1])
+    print("loss %.6f (reference %.6f); worst relative gradient error %.2e (%s)" % (float(loss), float(loss_ref), worst[1], worst[0]))
+    assert worst[1] < 1e-3, worst
+
+
+def test_three_train_steps_follow_torch_adamw():
+    """train.py:97-115 with batch_size 1: three iterations (loss, backward, AdamW(lr 1e-3, weight_decay 1e-2), zero_grad) on the
+    library against the same three iterations with torch on the CPU: losses and the parameters afterwards."""
+    from oracle.bsrnn_torch_cpu import TorchCpuBSRNN
+    from speechseparation_amd import spec, train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    v = spec.generate_bandsplits()[0]
+    sd = weights.synth_state_dict(None, seed=0)
+    mix = torch.from_numpy(weights.synth_waveform(2, 4 * 1024, seed=21))
+    speech = torch.from_numpy(weights.synth_waveform(2, 4 * 1024, seed=22))
+    ref = TorchCpuBSRNN(sd, v)
+    params = ref.trainable()
+    names = [k for k in params if params[k].numel() > 0]
+    opt_ref = torch.optim.AdamW([params[k] for k in names], lr=1e-3, weight_decay=1e-2)
+    win = torch.hann_window(2048)
+    l1 = torch.nn.L1Loss(reduction="mean")
+    ref_losses = []
+    for _ in range(3):
+        X = torch.stft(mix, n_fft=2048, hop_length=1024, return_complex=True, window=win)
+        y = ref.forward_differentiable(torch.stack((X.real, X.imag), dim=2).reshape(2, 2050, -1))
+        yc = y.reshape(2, -1, 2, y.shape[2])
+        Y = torch.complex(yc[:, :, 0, :], yc[:, :, 1, :])
+        xt = torch.istft(Y, n_fft=2048, hop_length=1024, window=win)
+        S = torch.stft(speech, n_fft=2048, hop_length=1024, return_complex=True, window=win)
+        loss = l1(xt, speech[:, :xt.shape[1]]) + l1(Y.real, S.real) + l1(Y.imag, S.imag)
+        loss.backward()
+        opt_ref.step()
+        opt_ref.zero_grad()
+        ref_losses.append(float(loss))
+
+    m = BSRNN().train()
+    m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+    m = m.to("cuda:0")
+    opt = train.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    losses = [float(train.train_step(m, opt, mix.cuda(), speech.cuda())) for _ in range(3)]
+    print("losses", losses, "reference", ref_losses)
+    assert losses[2] < losses[0]
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 2e-4 * abs(b)
+    got = dict(m.named_parameters())
+    worst = max((float((got[k].detach().cpu() - params[k].detach()).abs().max()), k) for k in names)
+    print("largest parameter difference after three steps: %.2e (%s)" % worst)
+    # AdamW's first steps move every parameter by ~lr whatever the gradient's size: sign-level noise of tiny gradients is amplified
+    assert worst[0] < 2e-3
