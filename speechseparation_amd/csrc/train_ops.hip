@@ -5,8 +5,8 @@
 // not yet tuned: the inference path's grouped / fused kernels are the model for the next pass.
 //   forward   y = act(x W^T + b)                                   x [M][K], W [N][K] (torch layout), y [M][N]
 //   backward  dp = dy * act'(y);  dx = dp W;  dW = dp^T x;  db = column sums of dp
-// Weight-gradient reductions over the M rows run in LSTM_TRAIN_CHUNKS fixed chunks that are then added in order:
-// gradients are bit-reproducible (no atomics).
+// Weight-gradient reductions over the M rows run in fixed row chunks (about 512 rows, at most LSTM_TRAIN_CHUNKS) that are then
+// added in order: gradients are bit-reproducible (no atomics).
 #include "kernels.h"
 
 namespace bsrnn {
@@ -149,9 +149,17 @@ __global__ void leaky_bwd_kernel(const float* __restrict__ dy, int lddy, const f
     dp[i] = y[(size_t)m * ldy + n] >= 0.f ? g : 0.01f * g;
 }
 
+// Row chunks of a reduction over M rows: about 512 rows each, at most LSTM_TRAIN_CHUNKS; a function of M only, so the order of
+// the additions - and with it every bit of a gradient - is the same from run to run.
+int chunk_count(int M)
+{
+    const int c = (M + 511) / 512;
+    return c < 1 ? 1 : (c > LSTM_TRAIN_CHUNKS ? LSTM_TRAIN_CHUNKS : c);
+}
 int rows_per_chunk(int M)
 {
-    return ((M + LSTM_TRAIN_CHUNKS - 1) / LSTM_TRAIN_CHUNKS + 15) / 16 * 16;
+    const int c = chunk_count(M);
+    return ((M + c - 1) / c + 15) / 16 * 16;
 }
 
 }  // namespace
@@ -172,17 +180,19 @@ void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* ou
                      int shift, hipStream_t s)
 {
     if (N1 <= 0 || N2 <= 0) return;
-    const int rpc = rows_per_chunk(M);
-    hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3((N1 + 63) / 64, (N2 + 63) / 64, LSTM_TRAIN_CHUNKS), dim3(256), 0, s, A, lda, B, ldb, scratch,
-                       M, N1, N2, rpc, L > 0 ? L : 1, shift);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N1 * N2 + 255) / 256), dim3(256), 0, s, scratch, out, N1 * N2, LSTM_TRAIN_CHUNKS);
+    const int rpc = rows_per_chunk(M), chunks = (M + rpc - 1) / rpc;
+    // a single chunk writes the result itself
+    hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3((N1 + 63) / 64, (N2 + 63) / 64, chunks), dim3(256), 0, s, A, lda, B, ldb,
+                       chunks > 1 ? scratch : out, M, N1, N2, rpc, L > 0 ? L : 1, shift);
+    if (chunks > 1) hipLaunchKernelGGL(reduce_partials_kernel, dim3((N1 * N2 + 255) / 256), dim3(256), 0, s, scratch, out, N1 * N2, chunks);
 }
 
 void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, int cols, hipStream_t s)
 {
     if (cols <= 0) return;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, LSTM_TRAIN_CHUNKS), dim3(256), 0, s, A, lda, scratch, M, cols, rows_per_chunk(M));
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols, LSTM_TRAIN_CHUNKS);
+    const int rpc = rows_per_chunk(M), chunks = (M + rpc - 1) / rpc;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, s, A, lda, chunks > 1 ? scratch : out, M, cols, rpc);
+    if (chunks > 1) hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols, chunks);
 }
 
 // ---------------------------------------------------------------------------------------------- AdamW (train.py:50)

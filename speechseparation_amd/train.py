@@ -276,10 +276,16 @@ class AdamW:
                                                     self.eps, self.weight_decay, self.t, _s(dev)))
 
 
-def train_step(model, optimizer, mix, speech):
-    """One iteration of the reference's loop (train.py:97-115 with batch_size 1): loss, backward, optimizer step, zero_grad."""
+def train_step(model, optimizer, mix, speech, group=None):
+    """One iteration of the reference's loop (train.py:97-115 with batch_size 1): loss, backward, optimizer step, zero_grad.
+    Under torch.distributed (one process per GPU, backend nccl = RCCL) every rank passes its own clip and the gradients are
+    averaged over the ranks in a few large buckets before the step (dist.all_reduce_gradients): data-parallel training."""
     loss, _ = train_loss(model, mix, speech)
     loss.backward()
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(group) > 1:
+        from .dist import all_reduce_gradients
+        all_reduce_gradients(model.parameters(), group=group)
     optimizer.step()
     optimizer.zero_grad()
     return loss.detach()

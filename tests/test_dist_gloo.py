@@ -90,3 +90,46 @@ def test_bench_refuses_a_world_that_contradicts_gpus():
     env = dict(os.environ, BSRNN_BENCH_PLUMBING="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speechseparation_amd.dist import all_reduce_gradients
+    torch.manual_seed(0)
+    shapes = [(256, 64), (256,), (0,), (768, 768), (64, 128), (2, 2)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    gen = torch.Generator().manual_seed(100 + rank)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=gen)
+    calls = all_reduce_gradients(params, bucket_bytes=1 << 20)   # 2.4 MB of gradients -> 2 buckets
+    if rank == 0:
+        q.put(([p.grad.numpy().copy() for p in params], calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_averages_in_buckets():
+    """Data-parallel training's exchange step (dist.all_reduce_gradients) on two gloo ranks: bucketed, averaged, in place."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads, calls = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    shapes = [(256, 64), (256,), (0,), (768, 768), (64, 128), (2, 2)]
+    want = []
+    for r in range(2):
+        gen = torch.Generator().manual_seed(100 + r)
+        want.append([torch.randn(s, generator=gen) for s in shapes])
+    assert calls == 2
+    for g, a, b in zip(grads, want[0], want[1]):
+        assert np.allclose(g, ((a + b) / 2).numpy(), rtol=0, atol=1e-7)
