@@ -153,8 +153,7 @@ int  bsrnn_dual_path(bsrnn_ctx* ctx, const float* z_dev, float* z_out_dev,
  *             are what backward reads.
  *   backward: dh [N][L][ndir*64] = gradient of the loss w.r.t. h  ->  dx [N][L][IN] (NULL: not wanted), dw_ih, dw_hh in the
  *             weights' layouts, db [ndir][256] (= the gradient of b_ih and of b_hh).  Gradients are overwritten, not
- *             accumulated; sums run in a fixed order (bit-reproducible).  Workspace is taken from the device's
- *             stream-ordered pool for the duration of the call. */
+ *             accumulated; sums run in a fixed order (bit-reproducible).  Workspace: a grow-only buffer of the context. */
 int  bsrnn_lstm_train_forward(bsrnn_ctx* ctx, const float* x_dev, const float* w_ih_dev, const float* w_hh_dev,
                               const float* bias_dev, float* h_dev, float* gates_dev, float* cells_dev,
                               int32_t N, int32_t L, int32_t IN, int32_t ndir, void* stream);
@@ -177,6 +176,12 @@ int  bsrnn_linear_train_backward(bsrnn_ctx* ctx, const float* x_dev, int32_t ldx
  * updated in place from the gradient g; `step` counts from 1 (bias correction).  n floats each, device pointers. */
 int  bsrnn_adamw_step(bsrnn_ctx* ctx, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* The same update for many parameter tensors at once (80 per launch, pointers passed in the kernel arguments): host arrays
+ * [n_tensors] of device pointers and of element counts. */
+int  bsrnn_adamw_step_multi(bsrnn_ctx* ctx, float* const* p_dev, const float* const* g_dev, float* const* m_dev, float* const* v_dev,
+                            const int64_t* sizes, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int32_t step, void* stream);
 
 /* ---- the STFT sandwich of the callers --------------------------------------------------
  * bsrnn_stft   = infer.py:29-33 (dup. m_dataset.py:187-190): wave_dev [R, n] ->

@@ -97,6 +97,8 @@ struct bsrnn_ctx {
     const void *bandW16[2][2], *timeW16[2];
     int *h_range = nullptr, *d_range = nullptr;    // range guard of the fp16x2 kernels: host-mapped word the kernels set                     // fp16x2 pieces in MFMA operand order (lstm.hip)
     float* d_tables = nullptr;
+    float* d_train_ws = nullptr;       // grow-only scratch of the training entry points (stream-ordered reuse: one call at a time)
+    size_t train_ws_floats = 0;
     int* d_colmap = nullptr;
     FftTables tb;
 
@@ -669,6 +671,7 @@ static void destroy_now(bsrnn_ctx* c)
     for (auto& kv : c->chain_tasks)
         for (int ch = 0; ch < 2; ++ch) (void)hipFree(kv.second.d[ch]);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_train_ws) (void)hipFree(c->d_train_ws);
     if (c->d_colmap) (void)hipFree(c->d_colmap);
     if (c->h_range) (void)hipHostFree(c->h_range);
     delete c;
@@ -1201,6 +1204,20 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
 // nn.LSTM of NormRNNResidual (bsrnn.py:66-72) forward with saves and backward through time (lstm_train.hip); what
 // loss.backward() runs for these layers in train.py:97-115.  Operands are the caller's device buffers (torch layouts);
 // nothing of the committed inference weights is used.
+// Scratch of the training entry points: one grow-only buffer per context.  Calls on a context are serialised (ENTER_CALL) and a
+// stream switch waits for the previous stream, so reuse in stream order is safe; growing synchronises the device once.
+static float* train_scratch(bsrnn_ctx* c, size_t floats)
+{
+    if (floats <= c->train_ws_floats) return c->d_train_ws;
+    (void)hipDeviceSynchronize();
+    if (c->d_train_ws) (void)hipFree(c->d_train_ws);
+    c->d_train_ws = nullptr; c->train_ws_floats = 0;
+    const size_t want = floats + floats / 4;
+    if (hipMalloc((void**)&c->d_train_ws, want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); c->d_train_ws = nullptr; return nullptr; }
+    c->train_ws_floats = want;
+    return c->d_train_ws;
+}
+
 static int train_args_ok(bsrnn_ctx* c, int32_t N, int32_t L, int32_t IN, int32_t ndir, const char* who)
 {
     if (!c) return fail(BSRNN_EARG, "null context");
@@ -1234,16 +1251,11 @@ int bsrnn_lstm_train_backward(bsrnn_ctx* c, const float* x, const float* h, cons
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
     // workspace in stream order: gate gradients of every (sequence, step, direction) + the partial sums of the reductions
-    const size_t n_dg = (size_t)N * L * ndir * 256, n_scr = lstm_train_scratch_floats(IN, ndir);
-    float* ws = nullptr;
-    if (hipMallocAsync((void**)&ws, (n_dg + n_scr) * sizeof(float), s) != hipSuccess || !ws) {
-        (void)hipGetLastError();
-        return fail(BSRNN_EHIP, "bsrnn_lstm_train_backward: out of device memory (%zu MB of workspace)", (n_dg + n_scr) * sizeof(float) >> 20);
-    }
+    const size_t n_dg = (size_t)N * L * ndir * 256, n_scr = lstm_train_scratch_floats(N, L, IN, ndir);
+    float* ws = train_scratch(c, n_dg + n_scr);
+    if (!ws) return fail(BSRNN_EHIP, "bsrnn_lstm_train_backward: out of device memory (%zu MB of workspace)", (n_dg + n_scr) * sizeof(float) >> 20);
     launch_lstm_train_backward(x, h, gates, cells, dh, w_ih, w_hh, ws, ws + n_dg, dx, dw_ih, dw_hh, db, N, L, IN, ndir, s);
-    const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(ws, s);
-    if (e != hipSuccess) return fail(BSRNN_EHIP, "bsrnn_lstm_train_backward: %s", hipGetErrorString(e));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1258,6 +1270,35 @@ int bsrnn_adamw_step(bsrnn_ctx* c, float* p, const float* g, float* m, float* v,
     ENTER_CALL(c, s);
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     launch_adamw(p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_adamw_step_multi(bsrnn_ctx* c, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* sizes,
+                           int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    if (!p || !g || !m || !v || !sizes || n_tensors < 1 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
+        return fail(BSRNN_EARG, "bsrnn_adamw_step_multi: bad arguments (n_tensors=%d step=%d)", n_tensors, step);
+    for (int i = 0; i < n_tensors; ++i)
+        if (!p[i] || !g[i] || !m[i] || !v[i] || sizes[i] < 0) return fail(BSRNN_EARG, "bsrnn_adamw_step_multi: tensor %d: null pointer or negative size", i);
+    for (int i = 0; i < n_tensors; ++i)
+        if (sizes[i] >= ((int64_t)1 << 31) - 1024) return fail(BSRNN_EARG, "bsrnn_adamw_step_multi: tensor %d has %lld elements (limit 2^31)", i, (long long)sizes[i]);
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    for (int i0 = 0; i0 < n_tensors; i0 += ADAM_GROUP) {
+        AdamGroup a;
+        a.count = std::min(ADAM_GROUP, n_tensors - i0);
+        a.first_block[0] = 0;
+        for (int j = 0; j < a.count; ++j) {
+            a.p[j] = p[i0 + j]; a.g[j] = g[i0 + j]; a.m[j] = m[i0 + j]; a.v[j] = v[i0 + j];
+            a.n[j] = (int)sizes[i0 + j];
+            a.first_block[j + 1] = a.first_block[j] + (a.n[j] + 1023) / 1024;
+        }
+        launch_adamw_group(a, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), s);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1287,15 +1328,10 @@ int bsrnn_linear_train_backward(bsrnn_ctx* c, const float* x, int32_t ldx, const
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
     const size_t n_scr = linear_train_scratch_floats(M, K, N, leaky != 0);
-    float* ws = nullptr;
-    if (hipMallocAsync((void**)&ws, n_scr * sizeof(float), s) != hipSuccess || !ws) {
-        (void)hipGetLastError();
-        return fail(BSRNN_EHIP, "bsrnn_linear_train_backward: out of device memory (%zu MB of workspace)", n_scr * sizeof(float) >> 20);
-    }
+    float* ws = train_scratch(c, n_scr);
+    if (!ws) return fail(BSRNN_EHIP, "bsrnn_linear_train_backward: out of device memory (%zu MB of workspace)", n_scr * sizeof(float) >> 20);
     launch_linear_train_backward(x, ldx, w, y, ldy, dy, lddy, dx, lddx, dw, db, ws, M, K, N, leaky != 0, s);
-    const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(ws, s);
-    if (e != hipSuccess) return fail(BSRNN_EHIP, "bsrnn_linear_train_backward: %s", hipGetErrorString(e));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1346,17 +1382,11 @@ int bsrnn_istft_backward(bsrnn_ctx* c, const float* dwave, float* dy, int32_t R,
     ENTER_CALL(c, s);
     int rc = ensure_ws(c, (size_t)R * T);
     if (rc) return rc;
-    float* ws = nullptr;
-    const size_t n_g = (size_t)R * (T - 1) * HOPS;
-    if (hipMallocAsync((void**)&ws, n_g * sizeof(float), s) != hipSuccess || !ws) {
-        (void)hipGetLastError();
-        return fail(BSRNN_EHIP, "bsrnn_istft_backward: out of device memory");
-    }
+    float* ws = train_scratch(c, (size_t)R * (T - 1) * HOPS);
+    if (!ws) return fail(BSRNN_EHIP, "bsrnn_istft_backward: out of device memory");
     launch_istft_backward(c->tb, dwave, ws, c->Yf, R, T, s);
     launch_from_frame_major(c->tb, c->Yf, dy, R, T, s);
-    const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(ws, s);
-    if (e != hipSuccess) return fail(BSRNN_EHIP, "bsrnn_istft_backward: %s", hipGetErrorString(e));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -136,11 +136,12 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const voi
 //   forward:  x [N][L][IN] -> h [N][L][ndir 64], gates [N][L][ndir][256] (after the non-linearities), cells [N][L][ndir][64]
 //   backward: dh [N][L][ndir 64] -> dx [N][L][IN] (or null), dw_ih, dw_hh, db (= db_ih = db_hh) in the weights' layouts;
 //             dg [N][L][ndir][256] and scratch [lstm_train_scratch_floats] are workspace
-constexpr int LSTM_TRAIN_CHUNKS = 64;        // row chunks of the weight-gradient reductions (summed in a fixed order)
+constexpr int LSTM_TRAIN_CHUNKS = 64;        // row chunks of the weight-gradient reductions (summed in a fixed order): ~512 rows each
+constexpr int LSTM_TRAIN_MAX_CHUNKS = 256;   // ... more, up to this, when the gradient has only a few 64 x 64 tiles
 // generic fp32 products of the training step (train_ops.hip): C (+)= A op(B) (+ bias) (LeakyReLU); out = A^T B with an optional
 // step shift of B's rows (h_prev); column sums.  Scratch = partial sums of the row chunks.
-size_t sgemm_tn_scratch_floats(int N1, int N2);
-size_t colsum_scratch_floats(int cols);
+size_t sgemm_tn_scratch_floats(int M, int N1, int N2);
+size_t colsum_scratch_floats(int M, int cols);
 void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, int M, int N, int K,
                   int accumulate, const float* bias, int leaky, hipStream_t stream);
 void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* out, float* scratch, int M, int N1, int N2, int L,
@@ -149,6 +150,15 @@ void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, i
 // one AdamW update of n parameters (torch.optim.AdamW semantics; bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t))
 void launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
                   float bc1, float bc2s, hipStream_t stream);
+// the same update for up to ADAM_GROUP tensors in one launch; everything travels by value in the kernel arguments
+constexpr int ADAM_GROUP = 80;
+struct AdamGroup {
+    float* p[ADAM_GROUP]; const float* g[ADAM_GROUP]; float* m[ADAM_GROUP]; float* v[ADAM_GROUP];
+    int n[ADAM_GROUP];                  // elements per tensor (< 2^31)
+    int first_block[ADAM_GROUP + 1];    // prefix sums of ceil(n / 1024)
+    int count;
+};
+void launch_adamw_group(const AdamGroup& a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, hipStream_t stream);
 // nn.Linear (+ LeakyReLU(0.01)): y = act(x W^T + b), W [N][K]; backward: dx (may be null), dW, db from dy (and y when leaky)
 size_t linear_train_scratch_floats(int M, int K, int N, int leaky);
 void launch_linear_train_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
@@ -156,7 +166,7 @@ void launch_linear_train_forward(const float* x, int ldx, const float* w, const 
 void launch_linear_train_backward(const float* x, int ldx, const float* w, const float* y, int ldy, const float* dy, int lddy,
                                   float* dx, int lddx, float* dw, float* db, float* scratch, int M, int K, int N, int leaky,
                                   hipStream_t stream);
-size_t lstm_train_scratch_floats(int IN, int ndir);
+size_t lstm_train_scratch_floats(int N, int L, int IN, int ndir);
 void launch_lstm_train_forward(const float* x, const float* w_ih, const float* w_hh, const float* bias, float* h, float* gates,
                                float* cells, int N, int L, int IN, int ndir, hipStream_t stream);
 void launch_lstm_train_backward(const float* x, const float* h, const float* gates, const float* cells, const float* dh,

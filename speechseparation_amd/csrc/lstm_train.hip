@@ -210,10 +210,11 @@ __global__ __launch_bounds__(256, 2) void lstm_train_bwd_kernel(const float* __r
 
 }  // namespace
 
-size_t lstm_train_scratch_floats(int IN, int ndir)
+size_t lstm_train_scratch_floats(int N, int L, int IN, int ndir)
 {
-    const size_t w = sgemm_tn_scratch_floats(256, IN > HID ? IN : HID), b = colsum_scratch_floats(ndir * 256);
-    return w > b ? w : b;
+    const int M = N * L;
+    const size_t w = sgemm_tn_scratch_floats(M, 256, IN > HID ? IN : HID), w2 = sgemm_tn_scratch_floats(M, 256, HID), b = colsum_scratch_floats(M, ndir * 256);
+    return w > w2 ? (w > b ? w : b) : (w2 > b ? w2 : b);
 }
 
 void launch_lstm_train_forward(const float* x, const float* w_ih, const float* w_hh, const float* bias, float* h, float* gates,

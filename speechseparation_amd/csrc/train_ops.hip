@@ -1,8 +1,10 @@
 // Training step: the plain matrix products around the recurrent kernels (lstm_train.hip) and the per-band Linear layers
 // (nn.Linear + LeakyReLU of bandFCs_pre / bandFCs / bandFCs_back / bandFCs_back_post and the fc / fc_in of NormRNNResidual,
 // bsrnn.py:333-376, :69, :74) as forward and backward, i.e. what torch.autograd runs for them in train.py:97-115.
-// Exact fp32 on v_mfma_f32_16x16x4_f32; first, correct versions (64 x 64 tiles through LDS, one K slab per barrier pair),
-// not yet tuned: the inference path's grouped / fused kernels are the model for the next pass.
+// Exact fp32 on v_mfma_f32_16x16x4_f32; first versions (64 x 64 tiles through LDS, one launch per band and layer; 60 TF on
+// the 768 x 768 layers at 8 064 rows, tools/train_gemm_bench.hip - a 128 x 64 tile with transposed LDS operands and 16-byte
+// LDS reads measured SLOWER, 23 - 41 TF: bank conflicts of the transposing stores): the inference path's grouped / fused
+// kernels are the model for the next pass.
 //   forward   y = act(x W^T + b)                                   x [M][K], W [N][K] (torch layout), y [M][N]
 //   backward  dp = dy * act'(y);  dx = dp W;  dW = dp^T x;  db = column sums of dp
 // Weight-gradient reductions over the M rows run in fixed row chunks (about 512 rows, at most LSTM_TRAIN_CHUNKS) that are then
@@ -29,24 +31,36 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
     v4f acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    float ra[4], rb[4];                                       // the next slab, in flight while the current one is multiplied
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
             const int ar = idx >> 4, ac = idx & 15;           // A slab: 64 rows x 16 k
             const int m = m0 + ar, k = k0 + ac;
-            sa[ar][ac] = (m < M && k < K) ? A[(size_t)m * lda + k] : 0.f;
+            ra[i] = (m < M && k < K) ? A[(size_t)m * lda + k] : 0.f;
             if (TRANS_B) {                                    // B^T slab from B [N][K]: k contiguous
                 const int bn = idx >> 4, bk = idx & 15;
                 const int n = n0 + bn, kk = k0 + bk;
-                sb[bk][bn] = (n < N && kk < K) ? B[(size_t)n * ldb + kk] : 0.f;
+                rb[i] = (n < N && kk < K) ? B[(size_t)n * ldb + kk] : 0.f;
             } else {                                          // B slab: 16 k x 64 columns
                 const int br = idx >> 6, bc = idx & 63;
                 const int kk = k0 + br, n = n0 + bc;
-                sb[br][bc] = (kk < K && n < N) ? B[(size_t)kk * ldb + n] : 0.f;
+                rb[i] = (kk < K && n < N) ? B[(size_t)kk * ldb + n] : 0.f;
             }
         }
+    };
+    if (K > 0) fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            sa[idx >> 4][idx & 15] = ra[i];
+            if (TRANS_B) sb[idx & 15][idx >> 4] = rb[i];
+            else sb[idx >> 6][idx & 63] = rb[i];
+        }
         __syncthreads();
+        if (k0 + 16 < K) fetch(k0 + 16);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const float a = sa[16 * wave + l15][4 * s + q];
@@ -73,11 +87,15 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 
 // Partial sums of C [N1][N2] = A^T B over the row chunk blockIdx.z: A [M][N1] (lda), B [M][N2] (ldb), both row-major.
 // `shift`: B's row for A's row m = (n, t) is (n, t + shift), zero where t + shift leaves [0, L) (h_prev of dW_hh); 0: same row.
+// TN_KS rows of both operands per barrier pair (16 measured 11 TF on the tall-skinny LSTM weight gradients: barrier-bound).
+#ifndef TN_KS
+#define TN_KS 32
+#endif
 __global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                                float* __restrict__ part, int M, int N1, int N2, int rows_per_chunk,
                                                                int L, int shift)
 {
-    __shared__ float sa[16][65], sb[16][65];
+    __shared__ float sa[TN_KS][65], sb[TN_KS][65];
     const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
     const int r_lo = blockIdx.z * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,23 +103,35 @@ __global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __re
     v4f acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int m0 = r_lo; m0 < r_hi; m0 += 16) {
+    // the next slab's elements travel in registers while the current one is multiplied (global latency behind the MFMAs)
+    float ra[TN_KS / 4], rb[TN_KS / 4];
+    auto fetch = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TN_KS / 4; ++i) {
             const int idx = tid + 256 * i;
             const int rr = idx >> 6, cc = idx & 63;
             const int m = m0 + rr;
-            sa[rr][cc] = (m < r_hi && i0 + cc < N1) ? A[(size_t)m * lda + i0 + cc] : 0.f;
+            ra[i] = (m < r_hi && i0 + cc < N1) ? A[(size_t)m * lda + i0 + cc] : 0.f;
             float bv = 0.f;
             if (m < r_hi && j0 + cc < N2) {
                 const int t = m % L + shift;
                 if (t >= 0 && t < L) bv = B[(size_t)(m + shift) * ldb + j0 + cc];
             }
-            sb[rr][cc] = bv;
+            rb[i] = bv;
+        }
+    };
+    if (r_lo < r_hi) fetch(r_lo);
+    for (int m0 = r_lo; m0 < r_hi; m0 += TN_KS) {
+#pragma unroll
+        for (int i = 0; i < TN_KS / 4; ++i) {
+            const int idx = tid + 256 * i;
+            sa[idx >> 6][idx & 63] = ra[i];
+            sb[idx >> 6][idx & 63] = rb[i];
         }
         __syncthreads();
+        if (m0 + TN_KS < r_hi) fetch(m0 + TN_KS);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < TN_KS / 4; ++s) {
             const float a = sa[4 * s + q][16 * wave + l15];       // A^T: tile row = column of A
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[4 * s + q][16 * j + l15], acc[j], 0, 0, 0);
@@ -149,23 +179,28 @@ __global__ void leaky_bwd_kernel(const float* __restrict__ dy, int lddy, const f
     dp[i] = y[(size_t)m * ldy + n] >= 0.f ? g : 0.01f * g;
 }
 
-// Row chunks of a reduction over M rows: about 512 rows each, at most LSTM_TRAIN_CHUNKS; a function of M only, so the order of
-// the additions - and with it every bit of a gradient - is the same from run to run.
-int chunk_count(int M)
+// Row chunks of a reduction over M rows into `tiles` output tiles: about 512 rows each, more when few tiles would leave the
+// chip empty (a 64 x 64 weight gradient is one tile), at most LSTM_TRAIN_CHUNKS and never under 32 rows; a function of the
+// shape only, so the order of the additions - and with it every bit of a gradient - is the same from run to run.
+int chunk_count(int M, int tiles)
 {
-    const int c = (M + 511) / 512;
-    return c < 1 ? 1 : (c > LSTM_TRAIN_CHUNKS ? LSTM_TRAIN_CHUNKS : c);
+    int c = (M + 511) / 512;
+    if (c > LSTM_TRAIN_CHUNKS) c = LSTM_TRAIN_CHUNKS;
+    const int fill = (1024 + tiles - 1) / tiles;          // few output tiles (a 256 x 64 LSTM gradient has 4): four workgroups per CU
+    if (c < fill) c = fill;
+    if (c > (M + 63) / 64) c = (M + 63) / 64;
+    return c < 1 ? 1 : (c > LSTM_TRAIN_MAX_CHUNKS ? LSTM_TRAIN_MAX_CHUNKS : c);
 }
-int rows_per_chunk(int M)
+int rows_per_chunk(int M, int tiles)
 {
-    const int c = chunk_count(M);
+    const int c = chunk_count(M, tiles);
     return ((M + c - 1) / c + 15) / 16 * 16;
 }
 
 }  // namespace
 
-size_t sgemm_tn_scratch_floats(int N1, int N2) { return (size_t)LSTM_TRAIN_CHUNKS * N1 * N2; }
-size_t colsum_scratch_floats(int cols) { return (size_t)LSTM_TRAIN_CHUNKS * cols; }
+size_t sgemm_tn_scratch_floats(int M, int N1, int N2) { return (size_t)chunk_count(M, ((N1 + 63) / 64) * ((N2 + 63) / 64)) * N1 * N2; }
+size_t colsum_scratch_floats(int M, int cols) { return (size_t)chunk_count(M, (cols + 255) / 256) * cols; }
 
 void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, int M, int N, int K,
                   int accumulate, const float* bias, int leaky, hipStream_t s)
@@ -180,7 +215,7 @@ void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* ou
                      int shift, hipStream_t s)
 {
     if (N1 <= 0 || N2 <= 0) return;
-    const int rpc = rows_per_chunk(M), chunks = (M + rpc - 1) / rpc;
+    const int rpc = rows_per_chunk(M, ((N1 + 63) / 64) * ((N2 + 63) / 64)), chunks = (M + rpc - 1) / rpc;
     // a single chunk writes the result itself
     hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3((N1 + 63) / 64, (N2 + 63) / 64, chunks), dim3(256), 0, s, A, lda, B, ldb,
                        chunks > 1 ? scratch : out, M, N1, N2, rpc, L > 0 ? L : 1, shift);
@@ -190,7 +225,7 @@ void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* ou
 void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, int cols, hipStream_t s)
 {
     if (cols <= 0) return;
-    const int rpc = rows_per_chunk(M), chunks = (M + rpc - 1) / rpc;
+    const int rpc = rows_per_chunk(M, (cols + 255) / 256), chunks = (M + rpc - 1) / rpc;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, s, A, lda, chunks > 1 ? scratch : out, M, cols, rpc);
     if (chunks > 1) hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols, chunks);
 }
@@ -211,6 +246,32 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     pi -= (lr / bc1) * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
 }
+// many tensors per launch: the pointers travel in the kernel arguments (copied at launch: nothing to keep alive, no table to
+// update in stream order); block b belongs to the tensor t with first_block[t] <= b < first_block[t + 1], 1024 elements per block
+__global__ __launch_bounds__(256) void adamw_group_kernel(AdamGroup a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s)
+{
+    int ti = 0;
+    while (ti + 1 < a.count && (int)blockIdx.x >= a.first_block[ti + 1]) ++ti;
+    float* p = a.p[ti]; const float* g = a.g[ti]; float* m = a.m[ti]; float* v = a.v[ti];
+    const int n = a.n[ti], base = ((int)blockIdx.x - a.first_block[ti]) * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = base + threadIdx.x + 256 * k;
+        if (i >= n) break;
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        pi -= (lr / bc1) * (mi / (__builtin_sqrtf(vi) / bc2s + eps));
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+void launch_adamw_group(const AdamGroup& a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, hipStream_t s)
+{
+    if (a.count <= 0 || a.first_block[a.count] <= 0) return;
+    hipLaunchKernelGGL(adamw_group_kernel, dim3(a.first_block[a.count]), dim3(256), 0, s, a, lr, b1, b2, eps, wd, bc1, bc2s);
+}
+
 void launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
                   float bc1, float bc2s, hipStream_t s)
 {
@@ -227,7 +288,7 @@ void launch_linear_train_forward(const float* x, int ldx, const float* w, const 
 
 size_t linear_train_scratch_floats(int M, int K, int N, int leaky)
 {
-    const size_t r = sgemm_tn_scratch_floats(N, K), c = colsum_scratch_floats(N);
+    const size_t r = sgemm_tn_scratch_floats(M, N, K), c = colsum_scratch_floats(M, N);
     return (r > c ? r : c) + (leaky ? (size_t)M * N : 0);
 }
 
@@ -240,7 +301,7 @@ void launch_linear_train_backward(const float* x, int ldx, const float* w, const
     const float* dp = dy;
     int lddp = lddy;
     if (leaky) {
-        const size_t r = sgemm_tn_scratch_floats(N, K), c = colsum_scratch_floats(N);
+        const size_t r = sgemm_tn_scratch_floats(M, N, K), c = colsum_scratch_floats(M, N);
         float* buf = scratch + (r > c ? r : c);
         hipLaunchKernelGGL(leaky_bwd_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, dy, lddy, y, ldy, buf, M, N);
         dp = buf; lddp = N;

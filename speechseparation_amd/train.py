@@ -265,15 +265,18 @@ class AdamW:
 
     @torch.no_grad()
     def step(self):
+        """All tensors that have a gradient in one launch (bsrnn_adamw_step_multi)."""
         self.t += 1
-        for p, m, v in zip(self.params, self.m, self.v):
-            if p.grad is None:
-                continue
-            g = _f32c(p.grad)
-            dev = p.device
-            with torch.cuda.device(dev):
-                _native.check(_lib.bsrnn_adamw_step(_context(dev), _p(p), _p(g), _p(m), _p(v), p.numel(), self.lr, self.betas[0], self.betas[1],
-                                                    self.eps, self.weight_decay, self.t, _s(dev)))
+        live = [(p, _f32c(p.grad), m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        if not live:
+            return
+        dev = live[0][0].device
+        n = len(live)
+        arr = lambda k: (ctypes.c_void_p * n)(*[t[k].data_ptr() for t in live])      # noqa: E731
+        sizes = (ctypes.c_int64 * n)(*[t[0].numel() for t in live])
+        with torch.cuda.device(dev):
+            _native.check(_lib.bsrnn_adamw_step_multi(_context(dev), arr(0), arr(1), arr(2), arr(3), sizes, n, self.lr, self.betas[0], self.betas[1],
+                                                      self.eps, self.weight_decay, self.t, _s(dev)))
 
 
 def train_step(model, optimizer, mix, speech, group=None):

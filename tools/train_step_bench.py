@@ -42,9 +42,22 @@ def main():
         loss = train.train_step(m, opt, mg, sg)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    # phases of one iteration, each closed by a device synchronise (so they add up to more than the pipelined step)
+    ph = {}
+    def lap(name, t):
+        torch.cuda.synchronize()
+        ph[name] = round(1e3 * (time.perf_counter() - t), 2)
+        return time.perf_counter()
+    t = time.perf_counter()
+    lo, _ = train.train_loss(m, mg, sg)
+    t = lap("forward+loss", t)
+    lo.backward()
+    t = lap("backward", t)
+    opt.step(); opt.zero_grad()
+    t = lap("adamw", t)
     T = 1 + n // 1024
     line = {"config": "train step (train.py:97-115, batch_size 1): %d rows x %.0f s @16 kHz (T=%d), exact-fp32 training kernels" % (a.rows, a.seconds, T),
-            "ms_per_step": round(ms, 2), "row_frames_per_s": round(a.rows * T / (ms * 1e-3), 1), "loss_after": round(float(loss), 5)}
+            "ms_per_step": round(ms, 2), "row_frames_per_s": round(a.rows * T / (ms * 1e-3), 1), "loss_after": round(float(loss), 5), "phases_ms": ph}
     if not a.no_cpu:
         from oracle.bsrnn_torch_cpu import TorchCpuBSRNN   # checker / CPU baseline only
         ref = TorchCpuBSRNN(sd, spec.generate_bandsplits()[0])
