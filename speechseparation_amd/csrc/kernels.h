@@ -144,8 +144,8 @@ size_t sgemm_tn_scratch_floats(int M, int N1, int N2);
 size_t colsum_scratch_floats(int M, int cols);
 void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, int M, int N, int K,
                   int accumulate, const float* bias, int leaky, hipStream_t stream);
-void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* out, float* scratch, int M, int N1, int N2, int L,
-                     int shift, hipStream_t stream);
+void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* out, float* colsum, float* scratch, int M, int N1, int N2,
+                     int L, int shift, hipStream_t stream);
 void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, int cols, hipStream_t stream);
 // one AdamW update of n parameters (torch.optim.AdamW semantics; bc1 = 1 - beta1^t, bc2s = sqrt(1 - beta2^t))
 void launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,

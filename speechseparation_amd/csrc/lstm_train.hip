@@ -240,11 +240,11 @@ void launch_lstm_train_backward(const float* x, const float* h, const float* gat
         const float* dgd = dg + (size_t)d * 256;                   // rows of 256 inside records of ndir 256
         const int ldg = ndir * 256;
         if (dx) launch_sgemm(dgd, ldg, w_ih + (size_t)d * 256 * IN, IN, 0, dx, IN, M, IN, 256, d > 0, nullptr, 0, s);
-        launch_sgemm_tn(dgd, ldg, x, IN, dw_ih + (size_t)d * 256 * IN, scratch, M, 256, IN, L, 0, s);          // dW_ih = dg^T x
+        // dW_ih = dg^T x, and the bias gradient (column sums of dg) from the same pass
+        launch_sgemm_tn(dgd, ldg, x, IN, dw_ih + (size_t)d * 256 * IN, db + (size_t)d * 256, scratch, M, 256, IN, L, 0, s);
         // dW_hh = dg^T h_prev: the forward pass of direction 0 read h_{t-1}, direction 1 h_{t+1}
-        launch_sgemm_tn(dgd, ldg, h + (size_t)d * HID, HO, dw_hh + (size_t)d * 256 * HID, scratch, M, 256, HID, L, d ? 1 : -1, s);
+        launch_sgemm_tn(dgd, ldg, h + (size_t)d * HID, HO, dw_hh + (size_t)d * 256 * HID, nullptr, scratch, M, 256, HID, L, d ? 1 : -1, s);
     }
-    launch_colsum(dg, ndir * 256, db, scratch, M, ndir * 256, s);      // db: all directions at once (columns = ndir 256)
 }
 
 }  // namespace bsrnn

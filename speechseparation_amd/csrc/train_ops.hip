@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 #endif
 __global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                                float* __restrict__ part, int M, int N1, int N2, int rows_per_chunk,
-                                                               int L, int shift)
+                                                               int L, int shift, int with_colsum)
 {
+    // with_colsum: the chunk's record is [N1 x N2 product | N1 column sums of A] (the bias gradient rides along: the A slab
+    // is in LDS anyway); the workgroups of the first column tile add them up
     __shared__ float sa[TN_KS][65], sb[TN_KS][65];
     const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
     const int r_lo = blockIdx.z * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __re
     for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
     // the next slab's elements travel in registers while the current one is multiplied (global latency behind the MFMAs)
     float ra[TN_KS / 4], rb[TN_KS / 4];
+    float csum = 0.f;
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < TN_KS / 4; ++i) {
@@ -133,12 +136,14 @@ __global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __re
 #pragma unroll
         for (int s = 0; s < TN_KS / 4; ++s) {
             const float a = sa[4 * s + q][16 * wave + l15];       // A^T: tile row = column of A
+            csum += a;                                            // (rows 4 s + q of column 16 wave + l15; unused unless with_colsum)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[4 * s + q][16 * j + l15], acc[j], 0, 0, 0);
         }
         __syncthreads();
     }
-    float* out = part + (size_t)blockIdx.z * N1 * N2;
+    const size_t rec = (size_t)N1 * N2 + (with_colsum ? N1 : 0);
+    float* out = part + (size_t)blockIdx.z * rec;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -146,15 +151,32 @@ __global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __re
             const int i = i0 + 16 * wave + 4 * q + r, jj = j0 + 16 * j + l15;
             if (i < N1 && jj < N2) out[(size_t)i * N2 + jj] = acc[j][r];
         }
+    if (with_colsum && blockIdx.y == 0) {        // the four row quarters of a column, added in a fixed order
+        sa[q][16 * wave + l15] = csum;
+        __syncthreads();
+        if (tid < 64 && i0 + tid < N1) out[(size_t)N1 * N2 + i0 + tid] = (sa[0][tid] + sa[1][tid]) + (sa[2][tid] + sa[3][tid]);
+    }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int chunks)
+// out[i] = sum over the chunks of part[c][i], i < n1 + n2 (records of n1 + n2 floats; the first n1 go to out1, the rest to out2).
+// Four partial sums over c = 0, 1, 2, 3 (mod 4), combined at the end: a fixed order, four loads in flight.
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out1, int n1, float* __restrict__ out2, int n2, int chunks)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = n1 + n2;
     if (i >= n) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
-    out[i] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 4 <= chunks; c += 4) {
+        s0 += part[(size_t)c * n + i];
+        s1 += part[(size_t)(c + 1) * n + i];
+        s2 += part[(size_t)(c + 2) * n + i];
+        s3 += part[(size_t)(c + 3) * n + i];
+    }
+    for (; c < chunks; ++c) s0 += part[(size_t)c * n + i];
+    const float r = (s0 + s1) + (s2 + s3);
+    if (i < n1) out1[i] = r;
+    else out2[i - n1] = r;
 }
 
 // column sums of A [M][cols] (lda) over row chunks (bias gradients); partials [chunks][cols]
@@ -199,7 +221,7 @@ int rows_per_chunk(int M, int tiles)
 
 }  // namespace
 
-size_t sgemm_tn_scratch_floats(int M, int N1, int N2) { return (size_t)chunk_count(M, ((N1 + 63) / 64) * ((N2 + 63) / 64)) * N1 * N2; }
+size_t sgemm_tn_scratch_floats(int M, int N1, int N2) { return (size_t)chunk_count(M, ((N1 + 63) / 64) * ((N2 + 63) / 64)) * ((size_t)N1 * N2 + N1); }
 size_t colsum_scratch_floats(int M, int cols) { return (size_t)chunk_count(M, (cols + 255) / 256) * cols; }
 
 void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, int M, int N, int K,
@@ -211,23 +233,24 @@ void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b,
     else hipLaunchKernelGGL(sgemm_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, bias, leaky);
 }
 
-void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* out, float* scratch, int M, int N1, int N2, int L,
+// out = A^T B; colsum (may be null) = column sums of A: both from one pass over the rows
+void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* out, float* colsum, float* scratch, int M, int N1, int N2, int L,
                      int shift, hipStream_t s)
 {
     if (N1 <= 0 || N2 <= 0) return;
     const int rpc = rows_per_chunk(M, ((N1 + 63) / 64) * ((N2 + 63) / 64)), chunks = (M + rpc - 1) / rpc;
-    // a single chunk writes the result itself
-    hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3((N1 + 63) / 64, (N2 + 63) / 64, chunks), dim3(256), 0, s, A, lda, B, ldb,
-                       chunks > 1 ? scratch : out, M, N1, N2, rpc, L > 0 ? L : 1, shift);
-    if (chunks > 1) hipLaunchKernelGGL(reduce_partials_kernel, dim3((N1 * N2 + 255) / 256), dim3(256), 0, s, scratch, out, N1 * N2, chunks);
+    const int n1 = N1 * N2, n2 = colsum ? N1 : 0;
+    hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3((N1 + 63) / 64, (N2 + 63) / 64, chunks), dim3(256), 0, s, A, lda, B, ldb, scratch,
+                       M, N1, N2, rpc, L > 0 ? L : 1, shift, colsum != nullptr);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n1 + n2 + 255) / 256), dim3(256), 0, s, scratch, out, n1, colsum, n2, chunks);
 }
 
 void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, int cols, hipStream_t s)
 {
     if (cols <= 0) return;
     const int rpc = rows_per_chunk(M, (cols + 255) / 256), chunks = (M + rpc - 1) / rpc;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, s, A, lda, chunks > 1 ? scratch : out, M, cols, rpc);
-    if (chunks > 1) hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols, chunks);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, s, A, lda, scratch, M, cols, rpc);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols, (float*)nullptr, 0, chunks);
 }
 
 // ---------------------------------------------------------------------------------------------- AdamW (train.py:50)
@@ -307,8 +330,8 @@ void launch_linear_train_backward(const float* x, int ldx, const float* w, const
         dp = buf; lddp = N;
     }
     if (dx && K > 0) launch_sgemm(dp, lddp, w, K, 0, dx, lddx, M, K, N, 0, nullptr, 0, s);       // dx = dp W
-    if (K > 0) launch_sgemm_tn(dp, lddp, x, ldx, dw, scratch, M, N, K, 1, 0, s);                  // dW = dp^T x
-    launch_colsum(dp, lddp, db, scratch, M, N, s);
+    if (K > 0) launch_sgemm_tn(dp, lddp, x, ldx, dw, db, scratch, M, N, K, 1, 0, s);              // dW = dp^T x, db = column sums of dp
+    else launch_colsum(dp, lddp, db, scratch, M, N, s);
 }
 
 }  // namespace bsrnn

@@ -25,7 +25,7 @@ int main()
                 CK(hipEventRecord(e0, 0));
                 if (kind == 0) launch_sgemm(A, K, B, K, 1, C, N, M, N, K, 0, nullptr, 0, 0);          // y = x W^T
                 else if (kind == 1) launch_sgemm(A, N, B, K, 0, C, K, M, K, N, 0, nullptr, 0, 0);     // dx = dp W
-                else launch_sgemm_tn(A, N, B, K, C, S, M, N, K, 1, 0, 0);                             // dW = dp^T x
+                else launch_sgemm_tn(A, N, B, K, C, nullptr, S, M, N, K, 1, 0, 0);                             // dW = dp^T x
                 CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
                 CK(hipEventElapsedTime(&ms[kind], e0, e1));
             }
