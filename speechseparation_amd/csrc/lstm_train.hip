@@ -164,35 +164,58 @@ __global__ __launch_bounds__(256, 2) void lstm_train_bwd_kernel(const float* __r
 #pragma unroll
     for (int s = 0; s < 64; ++s) wb[s] = w_hh[((size_t)dir * 256 + kperm(s, q)) * HID + unit];
 
-    float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc_next[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int step = 0; step < L; ++step) {
-        const int t = dir ? step : L - 1 - step;            // reverse of the forward order
+    // What a step reads of the forward pass, per cell of this lane: the four gates, the previous cell state and the output's
+    // gradient.  The NEXT step's set is requested while this step's recurrent product runs (a step is otherwise one global
+    // round trip long: 2.4 us at the time axis' 126 steps); the cell state of this step is the previous one of the next.
+    struct StepIn { float ig[4], fg[4], gg[4], og[4], cp[4], dh[4]; };
+    auto tstep = [&](int step) { return dir ? step : L - 1 - step; };      // reverse of the forward order
+    auto load_step = [&](int step, StepIn& in) {
+        const int t = tstep(step);
         const int tp = dir ? t + 1 : t - 1;                 // the step the forward pass ran before t (its c is c_prev)
         const bool has_prev = tp >= 0 && tp < L;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int n = n0 + 4 * q + r;
+            n = n < N ? n : N - 1;
+            const size_t rec = ((size_t)n * L + t) * ndir + dir;
+            const float* gp = gates + rec * 256 + unit;
+            in.ig[r] = gp[0]; in.fg[r] = gp[64]; in.gg[r] = gp[128]; in.og[r] = gp[192];
+            in.cp[r] = has_prev ? cells[(((size_t)n * L + tp) * ndir + dir) * HID + unit] : 0.f;
+            in.dh[r] = dh_out[((size_t)n * L + t) * HO + dir * HID + unit];
+        }
+    };
+    float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc_next[4] = {0.f, 0.f, 0.f, 0.f}, ct[4];
+    StepIn cur, nxt;
+    load_step(0, cur);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int n = n0 + 4 * q + r;
+        n = n < N ? n : N - 1;
+        ct[r] = cells[(((size_t)n * L + tstep(0)) * ndir + dir) * HID + unit];
+    }
+    for (int step = 0; step < L; ++step) {
+        const int t = tstep(step);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + 4 * q + r;
             float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
             if (n < N) {
-                const size_t rec = ((size_t)n * L + t) * ndir + dir;
-                const float* gp = gates + rec * 256 + unit;
-                const float ig = gp[0], fg = gp[64], gg = gp[128], og = gp[192];
-                const float ct = cells[rec * HID + unit];
-                const float cp = has_prev ? cells[(((size_t)n * L + tp) * ndir + dir) * HID + unit] : 0.f;
-                const float dh = dh_out[((size_t)n * L + t) * HO + dir * HID + unit] + dh_rec[r];
-                const float tc = tanh_f(ct);
+                const float ig = cur.ig[r], fg = cur.fg[r], gg = cur.gg[r], og = cur.og[r];
+                const float dh = cur.dh[r] + dh_rec[r];
+                const float tc = tanh_f(ct[r]);
                 dob = dh * tc * og * (1.0f - og);
                 const float dc = dh * og * (1.0f - tc * tc) + dc_next[r];
                 di = dc * gg * ig * (1.0f - ig);
-                df = dc * cp * fg * (1.0f - fg);
+                df = dc * cur.cp[r] * fg * (1.0f - fg);
                 dgg = dc * ig * (1.0f - gg * gg);
                 dc_next[r] = dc * fg;
-                float* op = dg + rec * 256 + unit;
+                float* op = dg + (((size_t)n * L + t) * ndir + dir) * 256 + unit;
                 op[0] = di; op[64] = df; op[128] = dgg; op[192] = dob;
             }
             float* lp = &gbuf[(4 * q + r) * SG + unit];
             lp[0] = di; lp[64] = df; lp[128] = dgg; lp[192] = dob;
         }
+        if (step + 1 < L) load_step(step + 1, nxt);
         __syncthreads();
         v4f acc = {0.f, 0.f, 0.f, 0.f};
         const float* ga = &gbuf[l15 * SG + 4 * q];
@@ -203,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void lstm_train_bwd_kernel(const float* __r
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wb[4 * j + e], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh_rec[r] = acc[r];
+        for (int r = 0; r < 4; ++r) { dh_rec[r] = acc[r]; ct[r] = cur.cp[r]; }
+        cur = nxt;
         __syncthreads();                                     // gbuf is rewritten by the next step
     }
 }
