@@ -140,6 +140,20 @@ constexpr int LSTM_TRAIN_CHUNKS = 64;        // row chunks of the weight-gradien
 constexpr int LSTM_TRAIN_MAX_CHUNKS = 256;   // ... more, up to this, when the gradient has only a few 64 x 64 tiles
 // generic fp32 products of the training step (train_ops.hip): C (+)= A op(B) (+ bias) (LeakyReLU); out = A^T B with an optional
 // step shift of B's rows (h_prev); column sums.  Scratch = partial sums of the row chunks.
+// a group of products in one launch (the same layer of all bands); passed by value in the kernel arguments
+constexpr int GEMM_GROUP = 12;
+struct TrainGemmJob {
+    const float* A; const float* B; float* C; const float* bias;
+    int lda, ldb, ldc;
+    int M, N, K;
+    int tiles_x, tiles_y, rpc;      // filled in by the launchers
+};
+struct TrainGemmGroup { TrainGemmJob j[GEMM_GROUP]; int first[GEMM_GROUP + 1]; int count; };
+struct ReduceJob { const float* part; float* out1; float* out2; int n1, n2, chunks; };
+struct ReduceGroup { ReduceJob j[GEMM_GROUP]; int first[GEMM_GROUP + 1]; int count; };
+void launch_sgemm_group(TrainGemmGroup& g, int trans_b, int accumulate, int leaky, hipStream_t stream);      // C_i (+)= A_i op(B_i) (+ bias_i)
+size_t tn_group_scratch_floats(const TrainGemmGroup& g);
+void launch_sgemm_tn_group(const TrainGemmGroup& g, float* scratch, int L, int shift, hipStream_t stream);   // C_i = A_i^T B_i, bias_i = column sums of A_i
 size_t sgemm_tn_scratch_floats(int M, int N1, int N2);
 size_t colsum_scratch_floats(int M, int cols);
 void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, int M, int N, int K,
@@ -159,6 +173,19 @@ struct AdamGroup {
     int count;
 };
 void launch_adamw_group(const AdamGroup& a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, hipStream_t stream);
+// nn.Linear (+ LeakyReLU(0.01)) for a group of layers that share the row count M (the same layer of all bands):
+struct LinearJob {
+    const float* x; int ldx;        // [M][K], row stride ldx
+    const float* w; const float* b; // W [N][K] (torch layout), b [N]
+    float* y; int ldy;              // forward output / backward input (read when leaky)
+    const float* dy; int lddy;      // backward: gradient of y
+    float* dx; int lddx;            // backward: gradient of x (null: not wanted)
+    float* dw; float* db;           // backward: gradients of W and b
+    int K, N;
+};
+void launch_linear_group_forward(const LinearJob* jobs, int n, int M, int leaky, hipStream_t stream);
+size_t linear_group_scratch_floats(const LinearJob* jobs, int n, int M, int leaky);
+void launch_linear_group_backward(const LinearJob* jobs, int n, int M, int leaky, float* scratch, hipStream_t stream);
 // nn.Linear (+ LeakyReLU(0.01)): y = act(x W^T + b), W [N][K]; backward: dx (may be null), dW, db from dy (and y when leaky)
 size_t linear_train_scratch_floats(int M, int K, int N, int leaky);
 void launch_linear_train_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,

@@ -17,15 +17,28 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// A launch runs a GROUP of products (the same layer of all bands: one launch instead of eleven); the jobs travel by value in
+// the kernel arguments, workgroup b belongs to the job with first[j] <= b < first[j + 1].
+__device__ __forceinline__ int find_job(const TrainGemmGroup& g, int b)
+{
+    int j = 0;
+    while (j + 1 < g.count && b >= g.first[j + 1]) ++j;
+    return j;
+}
+
 // C [M][N] (+)= A [M][K] op(B) (+ bias[N]) (LeakyReLU), op(B) = B [K][N] or (TRANS_B) B^T with B [N][K]; row-major with
 // leading dimensions.  64 x 64 tile per workgroup, wave w the 16-row strip w, K in slabs of 16 through LDS.
 template <bool TRANS_B>
-__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                    float* __restrict__ C, int ldc, int M, int N, int K, int accumulate,
-                                                    const float* __restrict__ bias, int leaky)
+__global__ __launch_bounds__(256) void sgemm_kernel(TrainGemmGroup g, int accumulate, int leaky)
 {
     __shared__ float sa[64][17], sb[16][65];
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int ji = find_job(g, blockIdx.x);
+    const TrainGemmJob& jb = g.j[ji];
+    const int local = blockIdx.x - g.first[ji];
+    const float* __restrict__ A = jb.A; const float* __restrict__ B = jb.B; float* __restrict__ C = jb.C;
+    const float* __restrict__ bias = jb.bias;
+    const int lda = jb.lda, ldb = jb.ldb, ldc = jb.ldc, M = jb.M, N = jb.N, K = jb.K;
+    const int m0 = (local % jb.tiles_x) * 64, n0 = (local / jb.tiles_x) * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     v4f acc[4];
@@ -91,15 +104,22 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 #ifndef TN_KS
 #define TN_KS 32
 #endif
-__global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                               float* __restrict__ part, int M, int N1, int N2, int rows_per_chunk,
-                                                               int L, int shift, int with_colsum)
+__global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(TrainGemmGroup g, int L, int shift)
 {
-    // with_colsum: the chunk's record is [N1 x N2 product | N1 column sums of A] (the bias gradient rides along: the A slab
+    // a job here: C = part (its chunk records), N = N1, K = N2, rpc rows per chunk, tiles_x x tiles_y tiles per chunk;
+    // bias != null: the chunk's record is [N1 x N2 product | N1 column sums of A] (the bias gradient rides along: the A slab
     // is in LDS anyway); the workgroups of the first column tile add them up
     __shared__ float sa[TN_KS][65], sb[TN_KS][65];
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-    const int r_lo = blockIdx.z * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
+    const int ji = find_job(g, blockIdx.x);
+    const TrainGemmJob& jb = g.j[ji];
+    const int local = blockIdx.x - g.first[ji];
+    const float* __restrict__ A = jb.A; const float* __restrict__ B = jb.B; float* __restrict__ part = jb.C;
+    const int lda = jb.lda, ldb = jb.ldb, M = jb.M, N1 = jb.N, N2 = jb.K, rows_per_chunk = jb.rpc;
+    const bool with_colsum = jb.bias != nullptr;
+    const int per_chunk = jb.tiles_x * jb.tiles_y, bz = local / per_chunk, bxy = local % per_chunk;
+    const int bx = bxy % jb.tiles_x, by = bxy / jb.tiles_x;
+    const int i0 = bx * 64, j0 = by * 64;
+    const int r_lo = bz * rows_per_chunk, r_hi = min(M, r_lo + rows_per_chunk);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     v4f acc[4];
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __re
         __syncthreads();
     }
     const size_t rec = (size_t)N1 * N2 + (with_colsum ? N1 : 0);
-    float* out = part + (size_t)blockIdx.z * rec;
+    float* out = part + (size_t)bz * rec;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -151,20 +171,25 @@ __global__ __launch_bounds__(256) void sgemm_tn_partial_kernel(const float* __re
             const int i = i0 + 16 * wave + 4 * q + r, jj = j0 + 16 * j + l15;
             if (i < N1 && jj < N2) out[(size_t)i * N2 + jj] = acc[j][r];
         }
-    if (with_colsum && blockIdx.y == 0) {        // the four row quarters of a column, added in a fixed order
+    if (with_colsum && by == 0) {                // the four row quarters of a column, added in a fixed order
         sa[q][16 * wave + l15] = csum;
         __syncthreads();
         if (tid < 64 && i0 + tid < N1) out[(size_t)N1 * N2 + i0 + tid] = (sa[0][tid] + sa[1][tid]) + (sa[2][tid] + sa[3][tid]);
     }
 }
 
-// out[i] = sum over the chunks of part[c][i], i < n1 + n2 (records of n1 + n2 floats; the first n1 go to out1, the rest to out2).
-// Four partial sums over c = 0, 1, 2, 3 (mod 4), combined at the end: a fixed order, four loads in flight.
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out1, int n1, float* __restrict__ out2, int n2, int chunks)
+// out[i] = sum over the chunks of part[c][i], i < n1 + n2 (records of n1 + n2 floats; the first n1 go to out1, the rest to out2),
+// for every job of the group (256 elements per workgroup).  Four partial sums over c = 0, 1, 2, 3 (mod 4), combined at the
+// end: a fixed order, four loads in flight.
+__global__ void reduce_partials_kernel(ReduceGroup g)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = n1 + n2;
+    int ji = 0;
+    while (ji + 1 < g.count && (int)blockIdx.x >= g.first[ji + 1]) ++ji;
+    const ReduceJob& jb = g.j[ji];
+    const int i = ((int)blockIdx.x - g.first[ji]) * blockDim.x + threadIdx.x;
+    const int n = jb.n1 + jb.n2, chunks = jb.chunks;
     if (i >= n) return;
+    const float* __restrict__ part = jb.part;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int c = 0;
     for (; c + 4 <= chunks; c += 4) {
@@ -175,8 +200,8 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, float* __
     }
     for (; c < chunks; ++c) s0 += part[(size_t)c * n + i];
     const float r = (s0 + s1) + (s2 + s3);
-    if (i < n1) out1[i] = r;
-    else out2[i - n1] = r;
+    if (i < jb.n1) jb.out1[i] = r;
+    else jb.out2[i - jb.n1] = r;
 }
 
 // column sums of A [M][cols] (lda) over row chunks (bias gradients); partials [chunks][cols]
@@ -190,15 +215,22 @@ __global__ void colsum_partial_kernel(const float* __restrict__ A, int lda, floa
     part[(size_t)blockIdx.y * cols + col] = s;
 }
 
-// dp = dy * (y >= 0 ? 1 : 0.01): the derivative of LeakyReLU(0.01) read off its output (0.01 > 0 keeps the sign)
-__global__ void leaky_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, float* __restrict__ dp,
-                                 int M, int N)
+// dp = dy * (y >= 0 ? 1 : 0.01): the derivative of LeakyReLU(0.01) read off its output (0.01 > 0 keeps the sign); jobs as above
+// with A = dy (lda), B = y (ldb), C = dp [M][N] dense, 1024 elements per workgroup
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(TrainGemmGroup g)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)M * N) return;
-    const int m = (int)(i / N), n = (int)(i % N);
-    const float g = dy[(size_t)m * lddy + n];
-    dp[i] = y[(size_t)m * ldy + n] >= 0.f ? g : 0.01f * g;
+    const int ji = find_job(g, blockIdx.x);
+    const TrainGemmJob& jb = g.j[ji];
+    const size_t base = (size_t)(blockIdx.x - g.first[ji]) * 1024;
+    const size_t total = (size_t)jb.M * jb.N;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = base + threadIdx.x + 256 * k;
+        if (i >= total) break;
+        const int m = (int)(i / jb.N), n = (int)(i % jb.N);
+        const float gr = jb.A[(size_t)m * jb.lda + n];
+        jb.C[i] = jb.B[(size_t)m * jb.ldb + n] >= 0.f ? gr : 0.01f * gr;
+    }
 }
 
 // Row chunks of a reduction over M rows into `tiles` output tiles: about 512 rows each, more when few tiles would leave the
@@ -224,13 +256,63 @@ int rows_per_chunk(int M, int tiles)
 size_t sgemm_tn_scratch_floats(int M, int N1, int N2) { return (size_t)chunk_count(M, ((N1 + 63) / 64) * ((N2 + 63) / 64)) * ((size_t)N1 * N2 + N1); }
 size_t colsum_scratch_floats(int M, int cols) { return (size_t)chunk_count(M, (cols + 255) / 256) * cols; }
 
+void launch_sgemm_group(TrainGemmGroup& g, int trans_b, int accumulate, int leaky, hipStream_t s)
+{
+    g.first[0] = 0;
+    for (int i = 0; i < g.count; ++i) {
+        TrainGemmJob& j = g.j[i];
+        j.tiles_x = (j.M + 63) / 64; j.tiles_y = (j.N + 63) / 64;
+        g.first[i + 1] = g.first[i] + ((j.M > 0 && j.N > 0) ? j.tiles_x * j.tiles_y : 0);
+    }
+    if (g.first[g.count] <= 0) return;
+    if (trans_b) hipLaunchKernelGGL(sgemm_kernel<true>, dim3(g.first[g.count]), dim3(256), 0, s, g, accumulate, leaky);
+    else hipLaunchKernelGGL(sgemm_kernel<false>, dim3(g.first[g.count]), dim3(256), 0, s, g, accumulate, leaky);
+}
+
 void launch_sgemm(const float* A, int lda, const float* B, int ldb, int trans_b, float* C, int ldc, int M, int N, int K,
                   int accumulate, const float* bias, int leaky, hipStream_t s)
 {
-    if (M <= 0 || N <= 0) return;
-    const dim3 grid((M + 63) / 64, (N + 63) / 64), block(256);
-    if (trans_b) hipLaunchKernelGGL(sgemm_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, bias, leaky);
-    else hipLaunchKernelGGL(sgemm_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, accumulate, bias, leaky);
+    TrainGemmGroup g;
+    g.count = 1;
+    g.j[0] = TrainGemmJob{A, B, C, bias, lda, ldb, ldc, M, N, K, 0, 0, 0};
+    launch_sgemm_group(g, trans_b, accumulate, leaky, s);
+}
+
+// Weight (and bias) gradients of a group: job i has A = dp_i [M][N1_i] (lda), B = x_i [M][N2_i] (ldb), N = N1, K = N2,
+// C = dW_i [N1][N2], bias = db_i (or null: no column sums).  Partials go to `scratch` (tn_group_scratch_floats).
+size_t tn_group_scratch_floats(const TrainGemmGroup& g)
+{
+    size_t tot = 0;
+    for (int i = 0; i < g.count; ++i) tot += sgemm_tn_scratch_floats(g.j[i].M, g.j[i].N, g.j[i].K);
+    return tot;
+}
+void launch_sgemm_tn_group(const TrainGemmGroup& in, float* scratch, int L, int shift, hipStream_t s)
+{
+    TrainGemmGroup g = in;
+    ReduceGroup rg;
+    rg.count = 0; rg.first[0] = 0;
+    g.first[0] = 0;
+    size_t off = 0;
+    for (int i = 0; i < g.count; ++i) {
+        TrainGemmJob& j = g.j[i];
+        const bool live = j.M > 0 && j.N > 0 && j.K > 0;
+        j.tiles_x = (j.N + 63) / 64; j.tiles_y = (j.K + 63) / 64;
+        j.rpc = live ? rows_per_chunk(j.M, j.tiles_x * j.tiles_y) : 1;
+        const int chunks = live ? (j.M + j.rpc - 1) / j.rpc : 0;
+        g.first[i + 1] = g.first[i] + j.tiles_x * j.tiles_y * chunks;
+        if (live) {
+            ReduceJob& r = rg.j[rg.count];
+            r.part = scratch + off; r.out1 = in.j[i].C; r.n1 = j.N * j.K; r.out2 = const_cast<float*>(in.j[i].bias); r.n2 = in.j[i].bias ? j.N : 0;
+            r.chunks = chunks;
+            rg.first[rg.count + 1] = rg.first[rg.count] + (r.n1 + r.n2 + 255) / 256;
+            ++rg.count;
+            j.C = scratch + off;
+            off += (size_t)chunks * ((size_t)r.n1 + r.n2);
+        }
+    }
+    if (g.first[g.count] <= 0) return;
+    hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3(g.first[g.count]), dim3(256), 0, s, g, L > 0 ? L : 1, shift);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(rg.first[rg.count]), dim3(256), 0, s, rg);
 }
 
 // out = A^T B; colsum (may be null) = column sums of A: both from one pass over the rows
@@ -238,11 +320,10 @@ void launch_sgemm_tn(const float* A, int lda, const float* B, int ldb, float* ou
                      int shift, hipStream_t s)
 {
     if (N1 <= 0 || N2 <= 0) return;
-    const int rpc = rows_per_chunk(M, ((N1 + 63) / 64) * ((N2 + 63) / 64)), chunks = (M + rpc - 1) / rpc;
-    const int n1 = N1 * N2, n2 = colsum ? N1 : 0;
-    hipLaunchKernelGGL(sgemm_tn_partial_kernel, dim3((N1 + 63) / 64, (N2 + 63) / 64, chunks), dim3(256), 0, s, A, lda, B, ldb, scratch,
-                       M, N1, N2, rpc, L > 0 ? L : 1, shift, colsum != nullptr);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n1 + n2 + 255) / 256), dim3(256), 0, s, scratch, out, n1, colsum, n2, chunks);
+    TrainGemmGroup g;
+    g.count = 1;
+    g.j[0] = TrainGemmJob{A, B, out, colsum, lda, ldb, 0, M, N1, N2, 0, 0, 0};
+    launch_sgemm_tn_group(g, scratch, L, shift, s);
 }
 
 void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, int cols, hipStream_t s)
@@ -250,7 +331,10 @@ void launch_colsum(const float* A, int lda, float* out, float* scratch, int M, i
     if (cols <= 0) return;
     const int rpc = rows_per_chunk(M, (cols + 255) / 256), chunks = (M + rpc - 1) / rpc;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, chunks), dim3(256), 0, s, A, lda, scratch, M, cols, rpc);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols, (float*)nullptr, 0, chunks);
+    ReduceGroup rg;
+    rg.count = 1; rg.first[0] = 0; rg.first[1] = (cols + 255) / 256;
+    rg.j[0] = ReduceJob{scratch, out, nullptr, cols, 0, chunks};
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(rg.first[1]), dim3(256), 0, s, rg);
 }
 
 // ---------------------------------------------------------------------------------------------- AdamW (train.py:50)
@@ -303,16 +387,89 @@ void launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float 
 }
 
 // ---------------------------------------------------------------------------------------------- nn.Linear (+ LeakyReLU)
+// A group = the same layer of several bands (or one layer): LinearJob i is y_i = act(x_i W_i^T + b_i) on M rows.
+void launch_linear_group_forward(const LinearJob* jobs, int n, int M, int leaky, hipStream_t s)
+{
+    for (int i0 = 0; i0 < n; i0 += GEMM_GROUP) {
+        TrainGemmGroup g;
+        g.count = n - i0 < GEMM_GROUP ? n - i0 : GEMM_GROUP;
+        for (int i = 0; i < g.count; ++i) {
+            const LinearJob& L = jobs[i0 + i];
+            g.j[i] = TrainGemmJob{L.x, L.w, L.y, L.b, L.ldx, L.K, L.ldy, M, L.N, L.K, 0, 0, 0};
+        }
+        launch_sgemm_group(g, 1, 0, leaky, s);
+    }
+}
+
+static size_t round4(size_t v) { return (v + 3) & ~(size_t)3; }
+size_t linear_group_scratch_floats(const LinearJob* jobs, int n, int M, int leaky)
+{
+    size_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t r = sgemm_tn_scratch_floats(M, jobs[i].N, jobs[i].K > 0 ? jobs[i].K : 1), c = colsum_scratch_floats(M, jobs[i].N);
+        tot += round4(r > c ? r : c) + (leaky ? round4((size_t)M * jobs[i].N) : 0);
+    }
+    return tot;
+}
+
+// Backward of the group: dp = dy * act'(y) (when leaky), dx = dp W (where wanted), dW = dp^T x and db = column sums of dp in one
+// pass.  scratch: linear_group_scratch_floats.
+void launch_linear_group_backward(const LinearJob* jobs, int n, int M, int leaky, float* scratch, hipStream_t s)
+{
+    if (M <= 0) return;
+    for (int i0 = 0; i0 < n; i0 += GEMM_GROUP) {
+        const int cnt = n - i0 < GEMM_GROUP ? n - i0 : GEMM_GROUP;
+        const float* dp[GEMM_GROUP];
+        int lddp[GEMM_GROUP];
+        TrainGemmGroup ew, gx, gw;
+        ew.count = gx.count = gw.count = 0;
+        ew.first[0] = 0;
+        // scratch of this chunk of jobs: first the dp buffers (when leaky), then ONE region for the reductions' partial records
+        for (int i = 0; i < cnt; ++i) {
+            const LinearJob& L = jobs[i0 + i];
+            dp[i] = L.dy; lddp[i] = L.lddy;
+            if (leaky) {
+                float* buf = scratch;
+                scratch += round4((size_t)M * L.N);
+                ew.j[ew.count] = TrainGemmJob{L.dy, L.y, buf, nullptr, L.lddy, L.ldy, L.N, M, L.N, 0, 0, 0, 0};
+                ew.first[ew.count + 1] = ew.first[ew.count] + (int)(((size_t)M * L.N + 1023) / 1024);
+                ++ew.count;
+                dp[i] = buf; lddp[i] = L.N;
+            }
+        }
+        float* const red = scratch;
+        for (int i = 0; i < cnt; ++i) {
+            const LinearJob& L = jobs[i0 + i];
+            const size_t r = sgemm_tn_scratch_floats(M, L.N, L.K > 0 ? L.K : 1), c = colsum_scratch_floats(M, L.N);
+            scratch += round4(r > c ? r : c);
+        }
+        if (ew.count && ew.first[ew.count] > 0) hipLaunchKernelGGL(leaky_bwd_kernel, dim3(ew.first[ew.count]), dim3(256), 0, s, ew);
+        for (int i = 0; i < cnt; ++i) {
+            const LinearJob& L = jobs[i0 + i];
+            if (L.dx && L.K > 0) gx.j[gx.count++] = TrainGemmJob{dp[i], L.w, L.dx, nullptr, lddp[i], L.K, L.lddx, M, L.K, L.N, 0, 0, 0};      // dx = dp W
+            if (L.K > 0) gw.j[gw.count++] = TrainGemmJob{dp[i], L.x, L.dw, L.db, lddp[i], L.ldx, 0, M, L.N, L.K, 0, 0, 0};              // dW = dp^T x, db
+            else launch_colsum(dp[i], lddp[i], L.db, red, M, L.N, s);       // (a layer without inputs: bias only; runs before the group below)
+        }
+        if (gx.count) launch_sgemm_group(gx, 0, 0, 0, s);
+        if (gw.count) {
+            launch_sgemm_tn_group(gw, red, 1, 0, s);
+        }
+    }
+}
+
 void launch_linear_train_forward(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int K, int N,
                                  int leaky, hipStream_t s)
 {
-    launch_sgemm(x, ldx, w, K, 1, y, ldy, M, N, K, 0, b, leaky, s);
+    LinearJob j{};
+    j.x = x; j.ldx = ldx; j.w = w; j.b = b; j.y = y; j.ldy = ldy; j.K = K; j.N = N;
+    launch_linear_group_forward(&j, 1, M, leaky, s);
 }
 
 size_t linear_train_scratch_floats(int M, int K, int N, int leaky)
 {
-    const size_t r = sgemm_tn_scratch_floats(M, N, K), c = colsum_scratch_floats(M, N);
-    return (r > c ? r : c) + (leaky ? (size_t)M * N : 0);
+    LinearJob j{};
+    j.K = K; j.N = N;
+    return linear_group_scratch_floats(&j, 1, M, leaky);
 }
 
 // dx may be null; y is only read when leaky.  scratch: linear_train_scratch_floats.
@@ -321,17 +478,9 @@ void launch_linear_train_backward(const float* x, int ldx, const float* w, const
                                   hipStream_t s)
 {
     if (M <= 0 || N <= 0) return;
-    const float* dp = dy;
-    int lddp = lddy;
-    if (leaky) {
-        const size_t r = sgemm_tn_scratch_floats(M, N, K), c = colsum_scratch_floats(M, N);
-        float* buf = scratch + (r > c ? r : c);
-        hipLaunchKernelGGL(leaky_bwd_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, dy, lddy, y, ldy, buf, M, N);
-        dp = buf; lddp = N;
-    }
-    if (dx && K > 0) launch_sgemm(dp, lddp, w, K, 0, dx, lddx, M, K, N, 0, nullptr, 0, s);       // dx = dp W
-    if (K > 0) launch_sgemm_tn(dp, lddp, x, ldx, dw, db, scratch, M, N, K, 1, 0, s);              // dW = dp^T x, db = column sums of dp
-    else launch_colsum(dp, lddp, db, scratch, M, N, s);
+    LinearJob j{};
+    j.x = x; j.ldx = ldx; j.w = w; j.y = const_cast<float*>(y); j.ldy = ldy; j.dy = dy; j.lddy = lddy; j.dx = dx; j.lddx = lddx; j.dw = dw; j.db = db; j.K = K; j.N = N;
+    launch_linear_group_backward(&j, 1, M, leaky, scratch, s);
 }
 
 }  // namespace bsrnn
