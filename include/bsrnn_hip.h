@@ -172,6 +172,17 @@ int  bsrnn_linear_train_backward(bsrnn_ctx* ctx, const float* x_dev, int32_t ldx
                                  int32_t ldy, const float* dy_dev, int32_t lddy, float* dx_dev, int32_t lddx,
                                  float* dw_dev, float* db_dev, int32_t M, int32_t K, int32_t N, int32_t leaky, void* stream);
 
+/* The same for n layers that share the row count M - the same Linear layer of all bands (bsrnn.py:406-411, :423-425 loop over
+ * the bands) - in grouped launches: host arrays [n] of device pointers / leading dimensions / K / N.  dx_dev[i] may be NULL. */
+int  bsrnn_linear_group_train_forward(bsrnn_ctx* ctx, int32_t n, const float* const* x_dev, const int32_t* ldx,
+                                      const float* const* w_dev, const float* const* b_dev, float* const* y_dev,
+                                      const int32_t* ldy, const int32_t* K, const int32_t* N, int32_t M, int32_t leaky, void* stream);
+int  bsrnn_linear_group_train_backward(bsrnn_ctx* ctx, int32_t n, const float* const* x_dev, const int32_t* ldx,
+                                       const float* const* w_dev, const float* const* y_dev, const int32_t* ldy,
+                                       const float* const* dy_dev, const int32_t* lddy, float* const* dx_dev, const int32_t* lddx,
+                                       float* const* dw_dev, float* const* db_dev, const int32_t* K, const int32_t* N,
+                                       int32_t M, int32_t leaky, void* stream);
+
 /* torch.optim.AdamW(model.parameters(), lr, weight_decay) of train.py:50, one tensor per call: p, m (exp_avg), v (exp_avg_sq)
  * updated in place from the gradient g; `step` counts from 1 (bias correction).  n floats each, device pointers. */
 int  bsrnn_adamw_step(bsrnn_ctx* ctx, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n,

@@ -22,6 +22,7 @@ SYMBOLS = [
     "bsrnn_sync", "bsrnn_evaluate", "bsrnn_io_count", "bsrnn_io_info", "bsrnn_mlp_fused",
     "bsrnn_lstm_train_forward", "bsrnn_lstm_train_backward", "bsrnn_linear_train_forward", "bsrnn_linear_train_backward",
     "bsrnn_istft_backward", "bsrnn_adamw_step", "bsrnn_adamw_step_multi",
+    "bsrnn_linear_group_train_forward", "bsrnn_linear_group_train_backward",
 ]
 METRIC_NAMES = ("loss", "sdr", "input_sdr", "sisdr", "l1_time", "l1_re", "l1_im", "separation_db")   # BSRNN_M_* order
 
@@ -68,6 +69,8 @@ def _load():
         "bsrnn_stft": (C.c_int, [vp, vp, vp, i32, i64, vp]),
         "bsrnn_istft": (C.c_int, [vp, vp, vp, i32, i32, vp]),
         "bsrnn_istft_backward": (C.c_int, [vp, vp, vp, i32, i32, vp]),
+        "bsrnn_linear_group_train_forward": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+        "bsrnn_linear_group_train_backward": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
         "bsrnn_adamw_step_multi": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
         "bsrnn_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
         "bsrnn_separate": (C.c_int, [vp, vp, vp, i32, i64, vp]),

@@ -1335,6 +1335,58 @@ int bsrnn_linear_train_backward(bsrnn_ctx* c, const float* x, int32_t ldx, const
     return 0;
 }
 
+// The same Linear layer of several bands (or any layers that share the row count M) in grouped launches: arrays [n] per field.
+int bsrnn_linear_group_train_forward(bsrnn_ctx* c, int32_t n, const float* const* x, const int32_t* ldx, const float* const* w,
+                                     const float* const* b, float* const* y, const int32_t* ldy, const int32_t* K, const int32_t* N,
+                                     int32_t M, int32_t leaky, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    if (n < 1 || n > 4096 || !x || !ldx || !w || !b || !y || !ldy || !K || !N || M < 1) return fail(BSRNN_EARG, "bsrnn_linear_group_train_forward: bad arguments");
+    std::vector<LinearJob> jobs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!x[i] || !w[i] || !b[i] || !y[i] || K[i] < 1 || N[i] < 1 || ldx[i] < K[i] || ldy[i] < N[i])
+            return fail(BSRNN_EARG, "bsrnn_linear_group_train_forward: job %d: bad arguments (K=%d N=%d ldx=%d ldy=%d)", i, K[i], N[i], ldx[i], ldy[i]);
+        LinearJob& j = jobs[i];
+        memset(&j, 0, sizeof j);
+        j.x = x[i]; j.ldx = ldx[i]; j.w = w[i]; j.b = b[i]; j.y = y[i]; j.ldy = ldy[i]; j.K = K[i]; j.N = N[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    launch_linear_group_forward(jobs.data(), n, M, leaky != 0, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bsrnn_linear_group_train_backward(bsrnn_ctx* c, int32_t n, const float* const* x, const int32_t* ldx, const float* const* w,
+                                      const float* const* y, const int32_t* ldy, const float* const* dy, const int32_t* lddy,
+                                      float* const* dx, const int32_t* lddx, float* const* dw, float* const* db,
+                                      const int32_t* K, const int32_t* N, int32_t M, int32_t leaky, void* stream)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    if (n < 1 || n > 4096 || !x || !ldx || !w || !dy || !lddy || !dx || !lddx || !dw || !db || !K || !N || M < 1 || (leaky && (!y || !ldy)))
+        return fail(BSRNN_EARG, "bsrnn_linear_group_train_backward: bad arguments");
+    std::vector<LinearJob> jobs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!x[i] || !w[i] || !dy[i] || !dw[i] || !db[i] || K[i] < 1 || N[i] < 1 || ldx[i] < K[i] || lddy[i] < N[i] || (dx[i] && lddx[i] < K[i]) ||
+            (leaky && (!y[i] || ldy[i] < N[i])))
+            return fail(BSRNN_EARG, "bsrnn_linear_group_train_backward: job %d: bad arguments (K=%d N=%d)", i, K[i], N[i]);
+        LinearJob& j = jobs[i];
+        memset(&j, 0, sizeof j);
+        j.x = x[i]; j.ldx = ldx[i]; j.w = w[i]; j.y = leaky ? const_cast<float*>(y[i]) : nullptr; j.ldy = leaky ? ldy[i] : 0;
+        j.dy = dy[i]; j.lddy = lddy[i]; j.dx = dx[i]; j.lddx = lddx[i]; j.dw = dw[i]; j.db = db[i]; j.K = K[i]; j.N = N[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    const size_t n_scr = linear_group_scratch_floats(jobs.data(), n, M, leaky != 0);
+    float* ws = train_scratch(c, n_scr);
+    if (!ws) return fail(BSRNN_EHIP, "bsrnn_linear_group_train_backward: out of device memory (%zu MB of workspace)", n_scr * sizeof(float) >> 20);
+    launch_linear_group_backward(jobs.data(), n, M, leaky != 0, ws, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // --------------------------------------------------------------------------- STFT sandwich
 int bsrnn_stft(bsrnn_ctx* c, const float* wave, float* x, int32_t R, int64_t n, void* stream)
 {

@@ -147,6 +147,66 @@ def _linear(x, lin, leaky):
     return LinearFunction.apply(x, lin.weight, lin.bias, leaky)
 
 
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else 0) for t in ts])
+
+
+def _i32_array(vals):
+    return (ctypes.c_int32 * len(vals))(*vals)
+
+
+class GroupedLinearFunction(torch.autograd.Function):
+    """n Linear (+ LeakyReLU) layers that share their row count - the same layer of all bands (the reference loops over the
+    bands, bsrnn.py:406-411 / :423-425) - in grouped launches: apply(leaky, n, x_0..x_{n-1}, w_0.., b_0..) -> (y_0, ..., y_{n-1})."""
+
+    @staticmethod
+    def forward(ctx, leaky, n, *ts):
+        xs = [_rows(t.detach()) for t in ts[:n]]
+        ws = [_f32c(t) for t in ts[n:2 * n]]
+        bs = [_f32c(t) for t in ts[2 * n:3 * n]]
+        M = xs[0].shape[0]
+        dev = xs[0].device
+        Ks = [w.shape[1] for w in ws]
+        Ns = [w.shape[0] for w in ws]
+        for x, w, b in zip(xs, ws, bs):
+            if not x.is_cuda or x.shape[0] != M or x.shape[1] != w.shape[1] or tuple(b.shape) != (w.shape[0],):
+                raise ValueError("GroupedLinear: every job needs cuda x [%d, K_i], weight [N_i, K_i], bias [N_i]" % M)
+        with torch.cuda.device(dev):
+            ys = [torch.empty((M, N), device=dev) for N in Ns]
+            _native.check(_lib.bsrnn_linear_group_train_forward(_context(dev), n, _ptr_array(xs), _i32_array([x.stride(0) for x in xs]), _ptr_array(ws),
+                                                                _ptr_array(bs), _ptr_array(ys), _i32_array(Ns), _i32_array(Ks), _i32_array(Ns),
+                                                                M, int(leaky), _s(dev)))
+        ctx.save_for_backward(*xs, *ws, *ys)
+        ctx.n, ctx.leaky = n, bool(leaky)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        xs, ws, ys = saved[:n], saved[n:2 * n], saved[2 * n:3 * n]
+        M = xs[0].shape[0]
+        dev = xs[0].device
+        Ks = [w.shape[1] for w in ws]
+        Ns = [w.shape[0] for w in ws]
+        with torch.cuda.device(dev):
+            dys = [_rows(d) if d is not None else torch.zeros((M, N), device=dev) for d, N in zip(dys, Ns)]
+            dxs = [torch.empty((M, K), device=dev) if ctx.needs_input_grad[2 + i] else None for i, K in enumerate(Ks)]
+            dws = [torch.empty_like(w) for w in ws]
+            dbs = [torch.empty((N,), device=dev) for N in Ns]
+            _native.check(_lib.bsrnn_linear_group_train_backward(
+                _context(dev), n, _ptr_array(xs), _i32_array([x.stride(0) for x in xs]), _ptr_array(ws), _ptr_array(ys), _i32_array(Ns),
+                _ptr_array(dys), _i32_array([d.stride(0) for d in dys]), _ptr_array(dxs), _i32_array(Ks), _ptr_array(dws), _ptr_array(dbs),
+                _i32_array(Ks), _i32_array(Ns), M, int(ctx.leaky), _s(dev)))
+        return (None, None, *dxs, *dws, *dbs)
+
+
+def _glinear(xs, lins, leaky):
+    """The same Sequential slot of every live band: lists of inputs and of nn.Linear modules -> list of outputs."""
+    n = len(xs)
+    return list(GroupedLinearFunction.apply(leaky, n, *xs, *[m.weight for m in lins], *[m.bias for m in lins]))
+
+
 def _rnn_block(m, x):
     """NormRNNResidual (bsrnn.py:78-87) on [N, L, 64]: fc_in -> 2-layer LSTM -> fc -> + x."""
     N, L, H = x.shape
@@ -158,25 +218,28 @@ def _rnn_block(m, x):
 
 def forward_train(model, x):
     """BSRNN.forward (bsrnn.py:385-443) with the autograd graph kept: every parameterised layer (the 110 Linear layers of the
-    band MLPs, fc_in / fc and the LSTM layers of the four dual-path blocks) runs the library's training kernels forward and
-    backward; the glue without parameters (slices, stack, permutes, residual adds, x * mask) is torch on the same device.
+    band MLPs - one grouped launch per Sequential slot over all bands -, fc_in / fc and the LSTM layers of the four dual-path
+    blocks) runs the library's training kernels forward and backward; the glue without parameters (slices, stack, permutes,
+    residual adds, x * mask) is torch on the same device.
     `model` is a speechseparation_amd.BSRNN on a cuda device; x [C, 2050, T] -> y [C, 2050, T]."""
     C, F2, T = x.shape
     v = model.band_widths
     H = band_features
-    xt = x.permute(0, 2, 1).reshape(C * T, F2)                    # frame rows (bsrnn.py:406)
-    residual, feats, pos = [], [], 0
-    for i, w in enumerate(v):
-        if w == 0:                                              # TrainableConstantModule (bsrnn.py:12-24)
-            residual.append(None)
-            feats.append(model.bandFCs[i][0].trainable_constant.expand(C * T, H))
-            continue
-        pre, fc = model.bandFCs_pre[i], model.bandFCs[i]
-        y = _linear(_linear(xt[:, pos:pos + 2 * w], pre[0], True), pre[2], True)
-        pos += 2 * w
-        residual.append(y)
-        feats.append(_linear(_linear(_linear(y, fc[0], True), fc[2], True), fc[4], False))
     K = len(v)
+    live = [i for i, w in enumerate(v) if w > 0]
+    xt = x.permute(0, 2, 1).reshape(C * T, F2)                    # frame rows (bsrnn.py:406)
+    pos, cols = 0, {}
+    for i in live:
+        cols[i] = (pos, pos + 2 * v[i])
+        pos += 2 * v[i]
+    slot = lambda mods, k: [mods[i][k] for i in live]             # noqa: E731  the k-th entry of every live band's Sequential
+    # BandSplit (bsrnn.py:404-415): bandFCs_pre (2 layers, its output is the mask's residual), bandFCs (3 layers)
+    h = _glinear([xt[:, a:b] for a, b in (cols[i] for i in live)], slot(model.bandFCs_pre, 0), True)
+    residual = _glinear(h, slot(model.bandFCs_pre, 2), True)
+    f = _glinear(residual, slot(model.bandFCs, 0), True)
+    f = _glinear(f, slot(model.bandFCs, 2), True)
+    f = dict(zip(live, _glinear(f, slot(model.bandFCs, 4), False)))
+    feats = [f[i] if i in f else model.bandFCs[i][0].trainable_constant.expand(C * T, H) for i in range(K)]   # bsrnn.py:12-24
     z = torch.stack(feats, 1).reshape(C, T, K, H)               # bsrnn.py:415
     for j, holder in enumerate(model.lstms):
         if j % 2 == 0:                                          # BandwiseLSTM (bsrnn.py:138-153)
@@ -184,14 +247,14 @@ def forward_train(model, x):
         else:                                                   # TimewiseLSTM (bsrnn.py:106-120)
             zt = z.permute(0, 2, 1, 3).reshape(C * K, T, H)
             z = _rnn_block(holder.m, zt).reshape(C, K, T, H).permute(0, 2, 1, 3)
-    parts = []
-    for i, w in enumerate(v):
-        if w == 0:
-            continue
-        back, post = model.bandFCs_back[i], model.bandFCs_back_post[i]
-        b = _linear(_linear(_linear(z[:, :, i, :].reshape(C * T, H), back[0], True), back[2], True), back[4], True)
-        parts.append(residual[i] + _linear(_linear(b, post[0], True), post[2], False))
-    mask = torch.cat(parts, 1).reshape(C, T, F2).permute(0, 2, 1)  # bsrnn.py:430-432
+    # MaskEstimation (bsrnn.py:420-430): bandFCs_back (3 layers, LeakyReLU after each), bandFCs_back_post (2 layers) + skip
+    zb = z.permute(2, 0, 1, 3).reshape(K, C * T, H)             # one contiguous [M, 64] block per band
+    b = _glinear([zb[i] for i in live], slot(model.bandFCs_back, 0), True)
+    b = _glinear(b, slot(model.bandFCs_back, 2), True)
+    b = _glinear(b, slot(model.bandFCs_back, 4), True)
+    b = _glinear(b, slot(model.bandFCs_back_post, 0), True)
+    b = _glinear(b, slot(model.bandFCs_back_post, 2), False)
+    mask = torch.cat([r + p for r, p in zip(residual, b)], 1).reshape(C, T, F2).permute(0, 2, 1)   # bsrnn.py:425-432
     return x * mask
 
 
@@ -258,6 +321,7 @@ class AdamW:
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
         self.t = 0
+        self._cache = None
 
     def zero_grad(self):
         for p in self.params:
@@ -267,15 +331,20 @@ class AdamW:
     def step(self):
         """All tensors that have a gradient in one launch (bsrnn_adamw_step_multi)."""
         self.t += 1
-        live = [(p, _f32c(p.grad), m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
-        if not live:
+        idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if not idx:
             return
-        dev = live[0][0].device
-        n = len(live)
-        arr = lambda k: (ctypes.c_void_p * n)(*[t[k].data_ptr() for t in live])      # noqa: E731
-        sizes = (ctypes.c_int64 * n)(*[t[0].numel() for t in live])
+        grads = [_f32c(self.params[i].grad) for i in idx]
+        dev = self.params[idx[0]].device
+        n = len(idx)
+        key = tuple(idx)
+        if self._cache is None or self._cache[0] != key:        # the static arrays (parameters, moments, sizes) are built once
+            arr = lambda ts: (ctypes.c_void_p * n)(*[ts[i].data_ptr() for i in idx])      # noqa: E731
+            self._cache = (key, arr(self.params), arr(self.m), arr(self.v), (ctypes.c_int64 * n)(*[self.params[i].numel() for i in idx]))
+        _, ap, am, av, sizes = self._cache
+        ag = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
         with torch.cuda.device(dev):
-            _native.check(_lib.bsrnn_adamw_step_multi(_context(dev), arr(0), arr(1), arr(2), arr(3), sizes, n, self.lr, self.betas[0], self.betas[1],
+            _native.check(_lib.bsrnn_adamw_step_multi(_context(dev), ap, ag, am, av, sizes, n, self.lr, self.betas[0], self.betas[1],
                                                       self.eps, self.weight_decay, self.t, _s(dev)))
 
 

@@ -269,3 +269,47 @@ def test_three_train_steps_follow_torch_adamw():
     print("largest parameter difference after three steps: %.2e (%s)" % worst)
     # AdamW's first steps move every parameter by ~lr whatever the gradient's size: sign-level noise of tiny gradients is amplified
     assert worst[0] < 2e-3
+
+
+@pytest.mark.parametrize("leaky", [True, False])
+def test_grouped_linear_matches_autograd(leaky):
+    """The same layer of several bands in grouped launches (bsrnn_linear_group_train_*): different widths, inputs that are column
+    blocks of one wide row buffer, one input that needs no gradient."""
+    from speechseparation_amd import train
+    M = 333
+    dims = [(2, 2), (6, 64), (96, 96), (514, 514), (64, 128)]
+    for seed in range(9, 60):
+        # LeakyReLU's derivative jumps at 0: data whose pre-activations all stay clear of it, so that a rounding-level
+        # difference between the two evaluations cannot pick the other branch (seed 9 has one of 171 162 values at 1e-7)
+        torch.manual_seed(seed)
+        wide = torch.randn(M, sum(k for k, _ in dims) + 7)
+        lins = [torch.nn.Linear(k, n) for k, n in dims]
+        xs, pos = [], 3
+        for k, _ in dims:
+            xs.append(wide[:, pos:pos + k].clone().requires_grad_(True))
+            pos += k
+        with torch.no_grad():
+            clear = min(float(lin(x).abs().min()) for lin, x in zip(lins, xs))
+        if clear > 1e-5:
+            break
+    assert clear > 1e-5
+    dys = [torch.randn(M, n) for _, n in dims]
+    act = torch.nn.functional.leaky_relu if leaky else (lambda t: t)
+    loss = sum((act(lin(x)) * dy).sum() for lin, x, dy in zip(lins, xs, dys))
+    loss.backward()
+
+    wg = wide.cuda()
+    xg, pos = [], 3
+    for i, (k, _) in enumerate(dims):
+        t = wg[:, pos:pos + k]
+        xg.append(t.requires_grad_(True) if i != 1 else t)          # job 1: no input gradient wanted
+        pos += k
+    ws = [lin.weight.detach().cuda().requires_grad_(True) for lin in lins]
+    bs = [lin.bias.detach().cuda().requires_grad_(True) for lin in lins]
+    ys = train.GroupedLinearFunction.apply(leaky, len(dims), *xg, *ws, *bs)
+    sum((y * dy.cuda()).sum() for y, dy in zip(ys, dys)).backward()
+    for i, (lin, x) in enumerate(zip(lins, xs)):
+        assert _rel(ys[i], act(lin(x))) < 2e-6
+        assert _rel(ws[i].grad, lin.weight.grad) < 1e-4 and _rel(bs[i].grad, lin.bias.grad) < 1e-4
+        if i != 1:
+            assert _rel(xg[i].grad, x.grad) < 1e-4
