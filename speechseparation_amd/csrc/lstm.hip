@@ -815,6 +815,10 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
             const int chunk = s / TCH, sin = s % TCH;
             const bool have_next = (chunk + 1) * TCH < T;
             if (sin == 0 && have_next) xnext = chunk_load(chunk + 1);
+            // x of the next chunk goes to LDS six steps after its load, at the TOP of the step: the wait in front of it then only
+            // covers operations a whole step old (behind this step's h store the compiler has to wait for vmcnt(0), store included).
+            // Its first reader is the batched input at the end of the next step, behind this step's barrier.
+            if (sin == TCH - 2 && have_next) chunk_store(chunk + 1, xnext);
             stamp(4);
             if (layer == 0) {
                 if (s < T) {
@@ -834,8 +838,6 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
                     stamp(2);
                 }
             }
-            // x of the next chunk is first read by the batched input at the end of the iteration before its first step
-            if (sin == TCH - 2 && have_next) chunk_store(chunk + 1, xnext);
             __syncthreads();
             stamp(3);
         }
