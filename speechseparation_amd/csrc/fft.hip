@@ -7,6 +7,7 @@
 // in double precision on the host.  These stages are HBM-bound (4 KiB in, 8.2 KiB out per
 // frame); their loads and stores are coalesced along the frame.
 #include "kernels.h"
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -85,10 +86,9 @@ __device__ __forceinline__ SplitCtx load_split(const FftTables& tb, int tid, boo
     SplitCtx c;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const int k = tid + 256 * i;
-        const bool ok = k <= 1024;
-        c.col[i] = ok && tb.colmap ? tb.colmap[k] : 2 * k;
-        c.tw[i] = ok ? tb.tw2048[k] : make_float2(0.f, 0.f);
+        const int k = i < 4 ? tid + 256 * i : 1024;          // fifth slot: bin 1024, computed and stored by every thread (see rfft_split_store)
+        c.col[i] = tb.colmap ? tb.colmap[k] : 2 * k;
+        c.tw[i] = tb.tw2048[k];
         if (i < 4) c.colr[i] = want_reverse ? (tb.colmap ? tb.colmap[1024 - k] : 2 * (1024 - k)) : 0;
     }
     return c;
@@ -98,9 +98,11 @@ __device__ __forceinline__ SplitCtx load_split(const FftTables& tb, int tid, boo
 __device__ __forceinline__ void rfft_split_store(const float2* Z, const SplitCtx& sc, float* __restrict__ out, int tid)
 {
 #pragma unroll
+    // No branch around a store: with the fifth (Nyquist) store conditional the compiler cannot count the stores in flight and
+    // waits for vmcnt(0) - the previous frame's stores included - in front of the next frame's samples.  Every thread stores
+    // bin 1024 instead (the same value to the same address).
     for (int i = 0; i < 5; ++i) {
-        const int k = tid + 256 * i;
-        if (k > 1024) break;
+        const int k = i < 4 ? tid + 256 * i : 1024;
         const float2 zk = Z[k & 1023];
         const float2 zc = cconj(Z[(1024 - k) & 1023]);
         const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
         for (int k = 0; k < 4; ++k) z0[tid + 256 * k] = make_float2(raw[k].x * win[k].x, raw[k].y * win[k].y);
         __syncthreads();
         raw[0] = raw[2]; raw[1] = raw[3];
-        if (t + 1 < t1) { raw[2] = sample2(t + 1, tid + 512); raw[3] = sample2(t + 1, tid + 768); }
+        { const int tn = t + 1 < t1 ? t + 1 : t; raw[2] = sample2(tn, tid + 512); raw[3] = sample2(tn, tid + 768); }      // (no branch: after the last frame a dummy reload)
         const float2* Z = fft1024<false>(z0, z1, twd, tid);
         rfft_split_store(Z, spl, X + ((size_t)r * T + t) * tb.ld, tid);
         __syncthreads();                          // Z (= z1) is overwritten by the next frame's first pass
@@ -308,16 +310,18 @@ __global__ __launch_bounds__(256) void istft_fused_kernel(FftTables tb, const fl
     const float* Yr = Y + (size_t)r * T * tb.ld;
     MergeRegs mr;
     irfft_load<false>(Yr + (size_t)b0 * tb.ld, spl, mr, tid);
-    for (int t = b0; t <= b1; ++t) {
+    // The first frame of the chunk only fills the carry; it is peeled so that the loop body has no branch around its loads and
+    // stores (the compiler then counts them and waits for the next spectrum with vmcnt(2) instead of vmcnt(0), stores included).
+    auto frame = [&](int t, auto first) {
         irfft_store(mr, spl, z0, tid);
         __syncthreads();
-        if (t < b1) irfft_load<false>(Yr + (size_t)(t + 1) * tb.ld, spl, mr, tid);
+        irfft_load<false>(Yr + (size_t)(t < b1 ? t + 1 : t) * tb.ld, spl, mr, tid);      // (after the last frame: a dummy reload)
         const float2* z = fft1024<true>(z0, z1, twd, tid);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int c = tid + 256 * k;
             const float2 a = z[c], b = z[c + 512];
-            if (t > b0) {
+            if (!decltype(first)::value) {
                 // same operation order as the two-pass version: (frame * 1/1024 * window) summed, then / envelope
                 const float2 v = make_float2((a.x * wlo[k].x + carry[k].x) * env[k].x, (a.y * wlo[k].y + carry[k].y) * env[k].y);
                 *reinterpret_cast<float2*>(out + (size_t)r * len + (size_t)(t - 1) * HOPS + 2 * c) = v;
@@ -325,7 +329,9 @@ __global__ __launch_bounds__(256) void istft_fused_kernel(FftTables tb, const fl
             carry[k] = make_float2(b.x * whi[k].x, b.y * whi[k].y);
         }
         __syncthreads();                          // z (= z1) is overwritten by the next frame's first pass
-    }
+    };
+    frame(b0, std::true_type());
+    for (int t = b0 + 1; t <= b1; ++t) frame(t, std::false_type());
 }
 
 void launch_istft(const FftTables& tb, const float* Y, float* out, int R, int T, hipStream_t s)
