@@ -218,13 +218,33 @@ def exact_f32_record(args):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, args.steps // 2)), "--warmup", str(args.warmup),
-           "--rows", str(args.rows), "--samples", str(args.samples), "--no-cpu-baseline", "--no-exact-f32"]
+           "--rows", str(args.rows), "--samples", str(args.samples), "--no-cpu-baseline", "--no-exact-f32", "--no-train-step"]
     try:
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         return {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "compute": {k: d["compute"][k] for k in ("gemm", "lstm")},
                 "note": "BSRNN_GEMM=f32 BSRNN_LSTM=f32: exact fp32 MFMA kernels of the same library, same workload, separate process"}
     except Exception as e:      # the sub-record is a report item, not part of `value`
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def train_step_record(args):
+    """One iteration of the reference's training loop (train.py:97-115) on the library's training kernels for the same batch
+    shape, measured in a child process before this one touches the GPU (tools/train_step_bench.py).
+    A report item, not part of `value`."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "tools", "train_step_bench.py"), "--rows", str(args.rows), "--seconds", str(args.samples / 16000.0),
+           "--steps", "10", "--no-cpu"]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        return {"ms_per_step": d["ms_per_step"], "row_frames_per_s": d["row_frames_per_s"], "phases_ms": d.get("phases_ms"),
+                "note": "forward + L1 tri-loss + backward + AdamW of m_dataset.train_infer / train.py:97-115 on the exact-fp32 training kernels, "
+                        "gradients verified against torch.autograd (tests/test_gpu_train.py); separate process"}
+    except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
@@ -255,6 +275,7 @@ def main():
     ap.add_argument("--samples", type=int, default=128000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-fp32 sub-record (a child process)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step sub-record (a child process)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with no launcher: become the launcher (N rank processes), before any GPU call
@@ -275,9 +296,11 @@ def main():
     if rehearse:
         local_rank = 0
     # exact-fp32 sub-record: a child process, run to completion before this process initialises the GPU
-    f32_rec = None
+    f32_rec = train_rec = None
     if world == 1 and not args.no_exact_f32 and not plumbing:
         f32_rec = exact_f32_record(args)
+    if world == 1 and not args.no_train_step and not plumbing:
+        train_rec = train_step_record(args)           # (child processes run before this one touches the GPU)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -407,6 +430,8 @@ def main():
         }
         if f32_rec is not None:
             line["exact_f32"] = f32_rec
+        if train_rec is not None:
+            line["train_step"] = train_rec
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(sd, args.rows, args.samples)
             line["cpu_baseline"] = cb

@@ -4,7 +4,7 @@
 set -e
 tag=$1
 export TMPDIR=/tmp
-B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-f32"
+B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-train-step"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- $B > gpurun_out/prof_$tag.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_fetch -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${tag}_write -- $B > /dev/null 2>&1
