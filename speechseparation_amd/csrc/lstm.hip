@@ -19,11 +19,8 @@
 #ifndef BAND_NLDS
 #define BAND_NLDS 2                 // second-piece weight blocks of the 128-input layer kept in LDS (3: 226 VGPRs, 2: 242, 1: 254)
 #endif
-#ifndef BAND_BIAS_LAST
-#define BAND_BIAS_LAST 0
-#endif
 #ifndef BAND_NO_PLANES
-#define BAND_NO_PLANES 0
+#define BAND_NO_PLANES 0            // measurement only: 1 = fp32 instead of fp16 planes between the two band layers (A/B, tools/precision_dual_path.py)
 #endif
 #ifndef BAND_ABL
 #define BAND_ABL 0                // measurement only (tools/lstm_h2_trace.hip): bit 1 no x staging, 2 no global h store, 4 no h publish, 8 no step barrier, 16 no MFMAs, 32 no transcendentals
@@ -330,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         if (BAND_ABL & 16) { asm volatile("" :: "v"(a0), "v"(a1), "v"(w2[0]), "v"(w2[1]), "v"(w2[2]), "v"(w2[3])); return; }
 #pragma unroll
         for (int gte = 0; gte < 4; ++gte)
-            hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b][gte][0], a0, b == 0 ? (BAND_BIAS_LAST ? zero4 : *reinterpret_cast<const v4f*>(bias_l + gte * HID)) : hi[gte], 0, 0, 0);
+            hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b][gte][0], a0, b == 0 ? *reinterpret_cast<const v4f*>(bias_l + gte * HID) : hi[gte], 0, 0, 0);
 #pragma unroll
         for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b][gte][0], a1, b == 0 ? zero4 : lo[gte], 0, 0, 0);
 #pragma unroll
@@ -398,12 +395,8 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         stamp(1);
 
         {   // cell update on 4-vectors (the adds / multiplies become v_pk_*, only the 5 exp + 5 rcp per cell stay scalar)
-            v4f pi = hi[0] + lo[0] * (1.f / 2048.f), pf = hi[1] + lo[1] * (1.f / 2048.f);
-            v4f pg = hi[2] + lo[2] * (1.f / 2048.f), po = hi[3] + lo[3] * (1.f / 2048.f);
-            if (BAND_BIAS_LAST) {
-                pi += *reinterpret_cast<const v4f*>(bias_l); pf += *reinterpret_cast<const v4f*>(bias_l + HID);
-                pg += *reinterpret_cast<const v4f*>(bias_l + 2 * HID); po += *reinterpret_cast<const v4f*>(bias_l + 3 * HID);
-            }
+            const v4f pi = hi[0] + lo[0] * (1.f / 2048.f), pf = hi[1] + lo[1] * (1.f / 2048.f);
+            const v4f pg = hi[2] + lo[2] * (1.f / 2048.f), po = hi[3] + lo[3] * (1.f / 2048.f);
             const v4f ig = rcp4(1.0f + exp2_4(pi * -1.44269504f)), fg = rcp4(1.0f + exp2_4(pf * -1.44269504f));
             const v4f gg = 2.0f * rcp4(1.0f + exp2_4(pg * -2.88539008f)) - 1.0f, og = rcp4(1.0f + exp2_4(po * -1.44269504f));
             cv = fg * cv + ig * gg;
