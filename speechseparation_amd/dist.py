@@ -75,7 +75,12 @@ def all_reduce_gradients(params, group=None, bucket_bytes=16 << 20, average=True
     calls = 0
     for bucket in gradient_buckets(list(params), bucket_bytes):
         flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":      # rehearsal on one GPU / CPU collectives: staged through the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         calls += 1
         if average:
             flat /= world

@@ -313,3 +313,72 @@ def test_grouped_linear_matches_autograd(leaky):
         assert _rel(ws[i].grad, lin.weight.grad) < 1e-4 and _rel(bs[i].grad, lin.bias.grad) < 1e-4
         if i != 1:
             assert _rel(xg[i].grad, x.grad) < 1e-4
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)        # both ranks share cuda:0 here: gradients staged through the host
+    from speechseparation_amd import train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    sd = weights.synth_state_dict(None, seed=0)
+    m = BSRNN().train()
+    m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+    m = m.to("cuda:0")
+    opt = train.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    mix = torch.from_numpy(weights.synth_waveform(2, 3 * 1024, seed=31 + rank)).cuda()       # every rank its own clip
+    speech = torch.from_numpy(weights.synth_waveform(2, 3 * 1024, seed=41 + rank)).cuda()
+    loss = train.train_step(m, opt, mix, speech)
+    out = {k: p.detach().cpu().numpy() for k, p in m.named_parameters() if p.numel() > 0}
+    q.put((rank, float(loss), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_train_step_averages_the_gradients_of_the_ranks():
+    """Two processes (one clip each, gloo rendezvous, both on cuda:0): after train_step both hold the same parameters, equal to one
+    process that averages the two clips' gradients itself before the same AdamW step."""
+    import socket
+    import torch.multiprocessing as mp
+    from speechseparation_amd import train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (lo, out)) for r, lo, out in (q.get(timeout=300) for _ in range(2)))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for k in got[0][1]:
+        assert np.array_equal(got[0][1][k], got[1][1][k]), k             # the ranks stay in lockstep
+
+    sd = weights.synth_state_dict(None, seed=0)
+    m = BSRNN().train()
+    m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+    m = m.to("cuda:0")
+    opt = train.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    grads = None
+    for r in range(2):
+        mix = torch.from_numpy(weights.synth_waveform(2, 3 * 1024, seed=31 + r)).cuda()
+        speech = torch.from_numpy(weights.synth_waveform(2, 3 * 1024, seed=41 + r)).cuda()
+        loss, _ = train.train_loss(m, mix, speech)
+        assert abs(float(loss) - got[r][0]) < 1e-6 * abs(float(loss))
+        loss.backward()
+        g = [p.grad.clone() if p.grad is not None else None for p in m.parameters()]
+        opt.zero_grad()
+        grads = g if grads is None else [a + b if a is not None else None for a, b in zip(grads, g)]
+    for p, g in zip(m.parameters(), grads):
+        if g is not None:
+            p.grad = g / 2
+    opt.step()
+    worst = max(float(np.abs(p.detach().cpu().numpy() - got[0][1][k]).max()) for k, p in m.named_parameters() if p.numel() > 0)
+    print("data-parallel step vs single process with averaged gradients: largest parameter difference %.2e" % worst)
+    assert worst < 1e-5
