@@ -115,6 +115,10 @@ void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 // Band-axis BLSTM layer (both directions in one launch): N sequences of length L.
 //   xin  [N][L][IN]           IN = 64 (layer 0, fc_in folded into W_ih) or 128 (layer 1)
 //   hout [N][L][128]          forward half at [0,64), backward half at [64,128)
+//        In the fp16x2 mode the IN = 64 launch (layer 0) writes its output as the two fp16 planes it already has for its own
+//        recurrence - per (sequence, step): [piece 0: 128 halves][piece 1: 128 halves], the same 512 bytes - and the IN = 128
+//        launch (layer 1) expects exactly that as xin: the pair is always launched back to back on the same buffer (api.hip);
+//        the exact-fp32 kernels (BSRNN_LSTM=f32, range-guard re-run) exchange plain fp32.
 //   wpk  packed [2 dir][4 wave][(IN+64)/4 step][4 gate][64 lane], bias [2][256]
 //   wpk16 (LSTM_FP16X2): the same matrix as two fp16 pieces in the f16 MFMA's B-operand order,
 //         [2 dir][4 wave][(IN+64)/32 blk][4 gate][2 piece][64 lane][8]
