@@ -311,6 +311,14 @@ def train_loss(model, mix, speech):
     return loss, x_time
 
 
+def sdr(x_time, s_time):
+    """`sdr` of train_infer (m_dataset.py:217-220): mean over the rows of 10 log10((sum s^2 + 1e-9) / (sum (x - s)^2 + 1e-9));
+    `train.py --loss_sdr` back-propagates its negative (train.py:100-101)."""
+    n2s = torch.sum(torch.square(s_time), dim=1) + 1e-9
+    n2d = torch.sum(torch.square(x_time - s_time), dim=1) + 1e-9
+    return (10 * torch.log10(n2s / n2d)).mean()
+
+
 # ------------------------------------------------------------------------------------------ optimizer and the step
 class AdamW:
     """torch.optim.AdamW(params, lr=0.001, weight_decay=0.01) of train.py:50 on the library's kernel (one launch per tensor)."""
@@ -348,12 +356,12 @@ class AdamW:
                                                       self.eps, self.weight_decay, self.t, _s(dev)))
 
 
-def train_step(model, optimizer, mix, speech, group=None):
-    """One iteration of the reference's loop (train.py:97-115 with batch_size 1): loss, backward, optimizer step, zero_grad.
-    Under torch.distributed (one process per GPU, backend nccl = RCCL) every rank passes its own clip and the gradients are
+def train_step(model, optimizer, mix, speech, group=None, loss_sdr=False):
+    """One iteration of the reference's loop (train.py:97-115 with batch_size 1): loss, backward (of the L1 tri-loss, or of -SDR with
+    loss_sdr as `train.py --loss_sdr`), optimizer step, zero_grad.  Under torch.distributed (one process per GPU, backend nccl = RCCL) every rank passes its own clip and the gradients are
     averaged over the ranks in a few large buckets before the step (dist.all_reduce_gradients): data-parallel training."""
-    loss, _ = train_loss(model, mix, speech)
-    loss.backward()
+    loss, x_time = train_loss(model, mix, speech)
+    (-sdr(x_time, speech[:, :x_time.shape[1]]) if loss_sdr else loss).backward()
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(group) > 1:
         from .dist import all_reduce_gradients

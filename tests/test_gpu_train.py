@@ -382,3 +382,35 @@ def test_data_parallel_train_step_averages_the_gradients_of_the_ranks():
     worst = max(float(np.abs(p.detach().cpu().numpy() - got[0][1][k]).max()) for k, p in m.named_parameters() if p.numel() > 0)
     print("data-parallel step vs single process with averaged gradients: largest parameter difference %.2e" % worst)
     assert worst < 1e-5
+
+
+def test_sdr_loss_gradient_matches_the_reference_option():
+    """`train.py --loss_sdr`: back-propagating -SDR of the time-domain estimate (m_dataset.py:217-220) instead of the L1 tri-loss."""
+    from oracle.bsrnn_torch_cpu import TorchCpuBSRNN
+    from speechseparation_amd import spec, train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    v = spec.generate_bandsplits()[0]
+    sd = weights.synth_state_dict(None, seed=0)
+    mix = torch.from_numpy(weights.synth_waveform(2, 5 * 1024, seed=51))
+    speech = torch.from_numpy(weights.synth_waveform(2, 5 * 1024, seed=52))
+    ref = TorchCpuBSRNN(sd, v)
+    params = ref.trainable()
+    win = torch.hann_window(2048)
+    X = torch.stft(mix, n_fft=2048, hop_length=1024, return_complex=True, window=win)
+    y = ref.forward_differentiable(torch.stack((X.real, X.imag), dim=2).reshape(2, 2050, -1))
+    yc = y.reshape(2, -1, 2, y.shape[2])
+    xt = torch.istft(torch.complex(yc[:, :, 0, :], yc[:, :, 1, :]), n_fft=2048, hop_length=1024, window=win)
+    st = speech[:, :xt.shape[1]]
+    sdr_ref = (10 * torch.log10((st.square().sum(1) + 1e-9) / ((xt - st).square().sum(1) + 1e-9))).mean()
+    (-sdr_ref).backward()
+
+    m = BSRNN().train()
+    m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+    m = m.to("cuda:0")
+    _, x_time = train.train_loss(m, mix.cuda(), speech.cuda())
+    val = train.sdr(x_time, speech.cuda()[:, :x_time.shape[1]])
+    (-val).backward()
+    assert abs(float(val.detach()) - float(sdr_ref.detach())) < 1e-4
+    worst = max(_rel(p.grad, params[n].grad) for n, p in m.named_parameters() if p.numel() > 0 and float(params[n].grad.abs().max()) > 0)
+    print("SDR %.4f dB (reference %.4f); worst relative gradient error %.2e" % (float(val.detach()), float(sdr_ref.detach()), worst))
+    assert worst < 1e-3
