@@ -338,10 +338,10 @@ class AdamW:
     @torch.no_grad()
     def step(self):
         """All tensors that have a gradient in one launch (bsrnn_adamw_step_multi)."""
-        self.t += 1
         idx = [i for i, p in enumerate(self.params) if p.grad is not None]
         if not idx:
-            return
+            return                                               # (torch counts a step only for parameters that have a gradient)
+        self.t += 1
         grads = [_f32c(self.params[i].grad) for i in idx]
         dev = self.params[idx[0]].device
         n = len(idx)
@@ -354,6 +354,20 @@ class AdamW:
         with torch.cuda.device(dev):
             _native.check(_lib.bsrnn_adamw_step_multi(_context(dev), ap, ag, am, av, sizes, n, self.lr, self.betas[0], self.betas[1],
                                                       self.eps, self.weight_decay, self.t, _s(dev)))
+        for i in idx:      # the kernel wrote the parameters behind torch's back: bump their version counters (BSRNN re-uploads
+            torch.autograd.graph.increment_version(self.params[i])      # its inference weights when a version changes)
+
+    def state_dict(self):
+        """What `torch.save(optimizer.state_dict(), "optimizer.pth")` of train.py:169-172 keeps: step count and both moments."""
+        return {"step": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                "exp_avg": [m.detach().cpu() for m in self.m], "exp_avg_sq": [v.detach().cpu() for v in self.v]}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["step"])
+        for dst, src in zip(self.m, sd["exp_avg"]):
+            dst.copy_(src)
+        for dst, src in zip(self.v, sd["exp_avg_sq"]):
+            dst.copy_(src)
 
 
 def train_step(model, optimizer, mix, speech, group=None, loss_sdr=False):

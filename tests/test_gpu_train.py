@@ -2,6 +2,8 @@
 bsrnn_lstm_train_forward / _backward) against torch.autograd on stock nn.LSTM on the CPU, the operator the reference's
 train step differentiates (bsrnn.py:66-72 inside train.py:97-115).  Exact-fp32 kernels: outputs to 2e-6, gradients to 1e-4
 of their largest element (sums over up to N*L = 3 000 rows in a different order than torch's)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -414,3 +416,29 @@ def test_sdr_loss_gradient_matches_the_reference_option():
     worst = max(_rel(p.grad, params[n].grad) for n, p in m.named_parameters() if p.numel() > 0 and float(params[n].grad.abs().max()) > 0)
     print("SDR %.4f dB (reference %.4f); worst relative gradient error %.2e" % (float(val.detach()), float(sdr_ref.detach()), worst))
     assert worst < 1e-3
+
+
+def test_train_entry_point_runs_epochs_validates_and_checkpoints(tmp_path):
+    """train.py (the reference's command line): two epochs on synthetic clips, validation through the inference path with the
+    UPDATED weights, checkpoints in the reference's file names, --resume."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, PYTHONPATH=REPO)
+    cmd = [sys.executable, os.path.join(REPO, "train.py"), "--synthetic", "3", "--seconds", "1", "--epochs", "2", "--batch_size", "2",
+           "--synthetic-weights", "0", "--outdir", str(tmp_path)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    losses = [float(l.split()[3]) for l in p.stdout.splitlines() if l.startswith("Epoch") and "Loss" in l]
+    vals = [float(l.split()[2]) for l in p.stdout.splitlines() if l.startswith("Validation Loss")]
+    print(p.stdout)
+    assert len(losses) == 2 and losses[1] < losses[0]
+    assert len(vals) == 2 and vals[1] != vals[0]                 # the validation pass sees the trained weights
+    for f in ("model.pth", "model-always.pth", "optimizer.pth", "optimizer-always.pth"):
+        assert (tmp_path / f).exists(), f
+    sd = torch.load(tmp_path / "model-always.pth", weights_only=True)
+    assert len(sd) == 288
+    p2 = subprocess.run(cmd + ["--resume", "--epochs", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    resumed = [float(l.split()[3]) for l in p2.stdout.splitlines() if l.startswith("Epoch") and "Loss" in l]
+    assert resumed and resumed[0] < losses[0]
