@@ -442,3 +442,33 @@ def test_train_entry_point_runs_epochs_validates_and_checkpoints(tmp_path):
     assert p2.returncode == 0, p2.stderr[-2000:]
     resumed = [float(l.split()[3]) for l in p2.stdout.splitlines() if l.startswith("Epoch") and "Loss" in l]
     assert resumed and resumed[0] < losses[0]
+
+
+def test_training_gradients_on_the_41_band_table():
+    """K = 42 (BASELINE config 5's band table): 41 live bands = four grouped launches per Sequential slot (12 jobs per launch),
+    band sequences of 42 steps; the gradients of all parameters against torch.autograd on the CPU restatement."""
+    from oracle.bsrnn_torch_cpu import TorchCpuBSRNN
+    from speechseparation_amd import spec, train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    v = spec.variant_bandsplits("41")
+    sd = weights.synth_state_dict(v, seed=3)
+    x = torch.from_numpy(weights.synth_tensor((2, 2050, 5), seed=7, scale=1.0))
+    target = torch.from_numpy(weights.synth_tensor((2, 2050, 5), seed=8, scale=1.0))
+    ref = TorchCpuBSRNN(sd, v)
+    params = ref.trainable()
+    (ref.forward_differentiable(x) - target).abs().mean().backward()
+    m = BSRNN(v).train()
+    m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+    m = m.to("cuda:0")
+    (train.forward_train(m, x.cuda()) - target.cuda()).abs().mean().backward()
+    worst = ("", 0.0)
+    n = 0
+    for name, p in m.named_parameters():
+        if p.numel() == 0:
+            continue
+        g_ref = params[name].grad
+        e = _rel(p.grad, g_ref) if float(g_ref.abs().max()) > 0 else float(p.grad.abs().max())
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        n += 1
+    print("41-band table: %d parameter tensors, worst relative gradient error %.2e (%s)" % (n, worst[1], worst[0]))
+    assert n > 800 and worst[1] < 1e-3, worst
