@@ -255,3 +255,24 @@ def test_weight_file_loader_rejects_malformed_files(built, tmp_path):
         assert lib.bsrnn_load_weights_file(ctx, str(tmp_path / "missing.bin").encode()) == EIO
     finally:
         lib.bsrnn_destroy(ctx)
+
+
+def test_train_entry_point_dataset_layout(tmp_path):
+    """train.py's data layout (m_dataset.samples(): <datapath>/<folder>/<clip>/mixture + speech) and its argument handling, on the CPU."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("train_entry", os.path.join(REPO, "train.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    for clip in ("b_clip", "a_clip", "incomplete"):
+        d = tmp_path / "tr" / clip
+        d.mkdir(parents=True)
+        (d / "mixture.wav").write_bytes(b"")
+        if clip != "incomplete":
+            (d / "speech.wav").write_bytes(b"")
+    (tmp_path / "tr" / "stray.txt").write_text("x")
+    got = mod.dataset(str(tmp_path), "tr")
+    assert [os.path.basename(os.path.dirname(a)) for a, _ in got] == ["a_clip", "b_clip"]
+    assert all(a.endswith("mixture.wav") and b.endswith("speech.wav") for a, b in got)
+    assert mod.dataset(str(tmp_path), "val") == []
+    with pytest.raises(SystemExit):
+        mod.main([])                                   # neither --datapath nor --synthetic
