@@ -203,7 +203,8 @@ def launch_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
     out0, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    for ln in out0.splitlines():              # stdout carries the JSON line only; anything a library printed there goes to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
