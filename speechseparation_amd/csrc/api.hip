@@ -137,6 +137,7 @@ struct bsrnn_stream {
     int C;
     float *buf, *prev, *state, *X, *Y, *chunk, *out;
     float* mixp;                       // device word holding the wet/dry control (read by the synthesis kernel)
+    int mix_bits = 0; bool mix_set = false; hipStream_t mix_stream = nullptr;      // what it was last set to (a 4-byte fill is a launch)
     float *h_in = nullptr, *h_out = nullptr;   // pinned staging for the host-buffer entry point
     // One step = ~27 tiny launches; its buffers are fixed, so the whole step is captured once into a
     // hipGraph and replayed (launch-bound inner loop: 477 us eager per step at C = 2).
@@ -1655,6 +1656,7 @@ int bsrnn_stream_reset(bsrnn_stream* st, void* stream)
     if (!st) return fail(BSRNN_EARG, "null stream");
     HIP_TRY(hipSetDevice(st->ctx->device));
     HIP_TRY(hipMemsetAsync(st->buf, 0, stream_total_floats(st->ctx, st->C) * sizeof(float), (hipStream_t)stream));
+    st->mix_set = false;                   // (the control word lives in the same allocation)
     return 0;
 }
 
@@ -1688,7 +1690,10 @@ int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mi
     if (chunk != st->chunk) HIP_TRY(hipMemcpyAsync(st->chunk, chunk, nb, hipMemcpyDeviceToDevice, s));
     int mix_bits;
     memcpy(&mix_bits, &mix, sizeof mix_bits);
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)st->mixp, mix_bits, 1, s));
+    if (!st->mix_set || st->mix_bits != mix_bits || st->mix_stream != s) {      // the control rarely changes: no fill launch per chunk
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)st->mixp, mix_bits, 1, s));
+        st->mix_bits = mix_bits; st->mix_set = true; st->mix_stream = s;
+    }
     if (st->use_graph && c->prof == 0 && !force_f32()) {
         // The captured step holds the context's workspace and weight-arena pointers.  A larger call on the context (workspace
         // regrown) or a re-commit of the parameters (arena rebuilt) since the capture changes ctx->gen: capture again
