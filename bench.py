@@ -40,7 +40,7 @@ DOMINANT = ("bandsplit_mlp", "mask_mlp")
 DTYPE_LABEL = {
     "f32": "f32 (exact fp32 MFMA)",
     "fp16x2": "f32 io/accumulate, fp16x2-split operands (22-bit operands, 3 f16 MFMA terms; a2*b2 term dropped)",
-    "fp16": "f16 operands, f32 accumulate/io (REDUCED PRECISION configuration)",
+    "fp16": "f16 operands, f32 accumulate/io (REDUCED PRECISION configuration; BASELINE config 2 names bf16: this is the fp16 one-term mode, 3 more mantissa bits than bf16)",
 }
 
 
@@ -83,9 +83,9 @@ def gemm_activation_bytes(v, flow="layers"):
 
 
 def host_cores():
-    """Threads for the CPU baseline: this process's share of the box (affinity and cgroup quota),
-    capped at BSRNN_CPU_THREADS (default 16 = one GPU's CPU share on the bench pool; asking
-    torch for every core of a 256-thread host from inside a 16-CPU cgroup thrashes)."""
+    """Threads for the CPU baseline (the ONE policy): this process's share of the box = CPU affinity
+    capped by the cgroup quota and by 16, the CPU share of one GPU slot on the bench pool.  (`os.cpu_count()` reports the host's 256 hardware threads from inside a 16-CPU cgroup;
+    asking torch for all of them thrashes.)  BSRNN_CPU_THREADS overrides."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -99,7 +99,10 @@ def host_cores():
                 n = min(n, max(1, q // p))
         except Exception:
             pass
-    return max(1, min(n, int(os.environ.get("BSRNN_CPU_THREADS", "16"))))
+    n = min(n, 16)              # the bench pool's CPU share of one GPU slot (what gpurun grants a one-GPU box), also where no quota is visible
+    if os.environ.get("BSRNN_CPU_THREADS"):
+        n = int(os.environ["BSRNN_CPU_THREADS"])
+    return max(1, n)
 
 
 # The ten grouped-GEMM launches of the two bracketed stages, by kernel instance (template arguments as rocprofv3
@@ -153,7 +156,7 @@ def build_model(device):
     return m.to(device), sd
 
 
-def cpu_baseline(sd, rows, n_samples, budget_s=12.0):
+def cpu_baseline(sd, rows, n_samples, budget_s=12.0, max_iters=7):
     from oracle.bsrnn_torch_cpu import TorchCpuBSRNN
     from speechseparation_amd import spec, weights
     cores = host_cores()
@@ -163,7 +166,7 @@ def cpu_baseline(sd, rows, n_samples, budget_s=12.0):
     m.separate(wave)                      # warm-up
     times = []
     t_all = time.perf_counter()
-    while len(times) < 7 and (time.perf_counter() - t_all) < budget_s:
+    while len(times) < max_iters and (time.perf_counter() - t_all) < budget_s:
         t0 = time.perf_counter()
         m.separate(wave)
         times.append(time.perf_counter() - t0)
@@ -335,6 +338,10 @@ def main():
     # of untimed steps runs before the caller's W warm-up steps whatever W is.  The timed region itself carries a
     # fixed ~0.4 ms (pipeline fill after the barrier, final synchronize): 1.22 ms/step at K = 20, 1.20 at K = 100.
     PREWARM = 64
+    # The timed loop opts out of the default range policy ("exact": every call waits for its kernels and checks the fp16x2
+    # range guard): K back-to-back asynchronous calls are what is measured.  The guard word is read once after
+    # the run (model.sync()): a violation would fail the run instead of going unnoticed.
+    model.set_range_policy("deferred")
     for _ in range(PREWARM):
         model.separate(wave, out=out)
     for _ in range(args.warmup):
@@ -357,10 +364,42 @@ def main():
         model.separate(wave, out=out)
     stages = model.stage_times(reset=True)
     model.set_profiling(False, device)
+    model.sync()                                  # raises if any step of the run left the fp16x2 range
+    # the reference's own operator on the same batch: BSRNN.forward on [R, 2050, T] (two layout transposes that `separate`
+    # does not pay, no STFT / iSTFT) - a report item beside `value`
+    xspec = model.stft(wave)
+    for _ in range(5):
+        model(xspec)
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    n_fwd = max(5, args.steps // 4)
+    for _ in range(n_fwd):
+        model(xspec)
+    torch.cuda.synchronize()
+    fwd_ms = 1e3 * (time.perf_counter() - tf0) / n_fwd
+    model.sync()
+    del xspec
+    # the same call under the default policy (synchronise + guard check per call): what a caller who does not opt out sees
+    model.set_range_policy("exact")
+    torch.cuda.synchronize()
+    te0 = time.perf_counter()
+    n_ex = max(5, args.steps // 4)
+    for _ in range(n_ex):
+        model.separate(wave, out=out)
+    torch.cuda.synchronize()
+    exact_ms = 1e3 * (time.perf_counter() - te0) / n_ex
+    my_ms = 1e3 * elapsed / args.steps
+    per_rank_ms = [my_ms]
     if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if rehearse else device, dtype=torch.float64)
+        cpu_or_dev = "cpu" if rehearse else device
+        t = torch.tensor([elapsed], device=cpu_or_dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [1e3 * float(a.item()) / args.steps for a in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if dist.get_world_size() != args.gpus:
+            sys.exit("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     frames_total = args.rows * world * T * args.steps
     value = frames_total / elapsed
@@ -418,7 +457,14 @@ def main():
             "value": round(value, 1), "unit": "row-frames/s", "n_gpus": world,
             "rccl_ranks": dist.get_world_size() if dist is not None else 1, "backend": (dist.get_backend() if dist is not None else "none"),
             "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "per_rank_ms": [round(v, 4) for v in per_rank_ms],
+            "per_rank_ms_min_max": [round(min(per_rank_ms), 4), round(max(per_rank_ms), 4)],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "range_guard": "deferred in the timed loop (explicit opt-out of the default per-call synchronise-and-check, include/bsrnn_hip.h); "
+                           "guard word read after the run: clean.  The same call under the default policy: %.4f ms per call" % exact_ms,
+            "forward_api": {"ms_per_call": round(fwd_ms, 4), "row_frames_per_s": round((hi - lo) * T / (fwd_ms * 1e-3), 1),
+                            "note": "BSRNN.forward on the [R, 2050, T] spectrum (the reference's operator, bsrnn.py:385): model only, with the two "
+                                    "layout transposes of that boundary; no STFT / iSTFT; this rank's %d rows" % (hi - lo)},
             "dtype": DTYPE_LABEL[cmode["gemm"]], "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks share cuda:0 over gloo; not a measurement)",
             "config": {"workload": "offline separate (STFT->BSRNN.forward->iSTFT), %d rows/GPU x %d samples @16 kHz (T=%d), K=12 bands, fp32"
                                    % (args.rows, args.samples, T),
@@ -437,6 +483,9 @@ def main():
             cb = cpu_baseline(sd, args.rows, args.samples)
             line["cpu_baseline"] = cb
             line["gpu_over_cpu"] = round(value / cb["value"], 1)
+            # BASELINE config 1 (infer.py on one 4 s mono 16 kHz mixture: 2 rows x 64 000 samples, T = 63), same policy
+            c1 = cpu_baseline(sd, 2, 64000, budget_s=4.0, max_iters=21)
+            line["cpu_baseline_config1"] = {k: c1[k] for k in ("value", "unit", "cores", "kind", "sample", "seconds_per_pass")}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define BSRNN_ABI_VERSION 1
+#define BSRNN_ABI_VERSION 2      /* 2: range policy (bsrnn_set_range_policy), training entry points, bsrnn_forward_chunk refuses aliased state */
 
 #define BSRNN_OK          0
 #define BSRNN_EARG        1   /* bad argument / shape */
@@ -63,14 +63,19 @@ const char* bsrnn_last_error(void);
  * variables BSRNN_GEMM (f32 | fp16x2 | fp16) and BSRNN_LSTM (f32 | fp16x2); default fp16x2 for both.
  * BSRNN_GEMM=fp16 is the one REDUCED-precision mode (plain fp16 operands in the Linear layers, one MFMA term,
  * fp32 accumulation: ~1e-3 of the output range); it exists for the "16-bit compute" benchmark configuration.
- * Range: the fp16x2 mode represents operands up to |a| = 65504 (spectra of audio in [-1, 1] stay below 1024).
- * A larger finite activation saturates, and the kernels notice (a host-visible flag).  What happens then:
- *   - SYNCHRONOUS entry points (bsrnn_evaluate, bsrnn_stream_step_host - they wait for their own kernels) check the flag
- *     before returning and, if it is set, run the same call again on the library's exact-fp32 kernels (fp32 weights are
- *     always resident; no range limit) from the same starting state: they return correct numbers with rc 0;
- *   - ASYNCHRONOUS entry points (everything that takes a stream and returns without waiting) cannot know: the NEXT call
- *     on the context, bsrnn_sync or bsrnn_stream_get_state fails with BSRNN_ERANGE ("an earlier call ... saturated"),
- *     once.  The caller then repeats the work after rescaling, or in a process started with BSRNN_GEMM=f32 BSRNN_LSTM=f32.
+ * Range: the fp16x2 mode represents operands up to |a| = 65504 (spectra of audio in [-1, 1] stay below 1024).  A larger
+ * finite activation cannot be represented; the kernels notice (a host-visible guard word).  What happens then is the
+ * context's RANGE POLICY (bsrnn_set_range_policy):
+ *   - BSRNN_RANGE_EXACT (default): every model entry point (bsrnn_forward, _forward_chunk, _forward_recurrent, _dual_path,
+ *     _separate, _stream_step, _evaluate) waits for its own kernels before it returns, looks at the guard and, if it is set,
+ *     runs the same call again on the library's exact-fp32 kernels (fp32 weights are always resident; no range limit) from
+ *     the same inputs / the same starting state: rc 0 always comes with correct numbers, as from the reference.  The price
+ *     is one stream synchronisation per call.
+ *   - BSRNN_RANGE_DEFERRED: the entry points return without waiting (launch pipelines, the benchmark loop).  A violation is
+ *     reported late: the NEXT call on the context, bsrnn_sync or bsrnn_stream_get_state fails with BSRNN_ERANGE, once, and
+ *     the results of the call that caused it are invalid (not-a-number or nonsense, never silently plausible saturated
+ *     values: nothing is clamped).  The caller repeats the work under the default policy.
+ *   bsrnn_stream_step_host always behaves as under BSRNN_RANGE_EXACT (it waits for its kernels anyway).
  * NaN / Inf inputs are not range errors: they come out as NaN, as they do from the reference. */
 const char* bsrnn_compute_mode(void);
 
@@ -85,6 +90,11 @@ int  bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx*
 void bsrnn_destroy(bsrnn_ctx* ctx);
 int  bsrnn_n_bands(const bsrnn_ctx* ctx);
 int  bsrnn_device(const bsrnn_ctx* ctx);
+/* Range policy of the split-precision modes (see bsrnn_compute_mode above); default BSRNN_RANGE_EXACT. */
+#define BSRNN_RANGE_DEFERRED 0
+#define BSRNN_RANGE_EXACT    1
+int  bsrnn_set_range_policy(bsrnn_ctx* ctx, int32_t policy);
+int  bsrnn_get_range_policy(const bsrnn_ctx* ctx);
 /* 1 when the committed context runs the per-band MLP chains (bsrnn.py:404-415, :420-443) as fused launches (one workgroup =
  * one band's five Linear layers, intermediates in LDS; the default), 0 when it runs one grouped launch per layer: the
  * exact-fp32 mode, BSRNN_MLP=layers (A/B), or a band table with a band too wide for the fused kernel's LDS image

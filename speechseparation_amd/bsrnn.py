@@ -91,6 +91,9 @@ class BSRNN(nn.Module):
         self._ctx = None
         self._ctx_device = None
         self._pushed_fingerprint = None
+        self._plist = None                  # cached parameter tensors (the module tree is fixed after construction)
+        self._epoch = 0                     # bumped by everything that may rebind parameter storage (_apply, load_state_dict)
+        self._range_policy = _native.RANGE_EXACT
 
     # ------------------------------------------------------------------ native context / weights
     def __del__(self):
@@ -101,7 +104,33 @@ class BSRNN(nn.Module):
             pass
 
     def _fingerprint(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """Cheap identity of the current weights: every in-place edit of a parameter bumps its tensor's `_version`; `.to()` /
+        `.cuda()` / `.float()` (all through `_apply`) and `load_state_dict` bump `_epoch`.  One attribute read per parameter
+        (a walk of `self.parameters()` with `data_ptr()` cost more than the GPU work of a streaming step it guarded)."""
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        return (self._epoch,) + tuple(p._version for p in self._plist)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._plist = None
+        self._epoch += 1
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._plist = None
+        self._epoch += 1
+        return out
+
+    def set_range_policy(self, policy):
+        """'exact' (default): every call waits for its kernels and, if an activation left the fp16x2 range (|a| > 65504),
+        is run again on the exact-fp32 kernels before it returns - results always match the reference's forward.
+        'deferred': calls return without waiting (benchmark loops, launch pipelines); a violation surfaces as a NativeError
+        at the next call on this model (include/bsrnn_hip.h, bsrnn_set_range_policy)."""
+        self._range_policy = {"exact": _native.RANGE_EXACT, "deferred": _native.RANGE_DEFERRED}[policy]
+        if self._ctx is not None:
+            _check(_lib.bsrnn_set_range_policy(self._ctx, self._range_policy))
 
     def _context(self, device):
         dev_index = device.index if device.index is not None else torch.cuda.current_device()
@@ -113,6 +142,7 @@ class BSRNN(nn.Module):
             ctx = ctypes.c_void_p()
             _check(_lib.bsrnn_create(dev_index, widths, len(self.band_widths), ctypes.byref(ctx)))
             self._ctx, self._ctx_device, self._pushed_fingerprint = ctx, dev_index, None
+            _check(_lib.bsrnn_set_range_policy(ctx, self._range_policy))
         fp = self._fingerprint()
         if fp != self._pushed_fingerprint:
             for key, val in self.state_dict().items():
@@ -127,9 +157,18 @@ class BSRNN(nn.Module):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         return "fused" if _lib.bsrnn_mlp_fused(self._context(dev)) == 1 else "layers"
 
+    def sync(self, device=None):
+        """Wait for this model's work on the current stream of `device`; raises if a call made under the 'deferred' range
+        policy left the fp16x2 range (bsrnn_sync)."""
+        dev = torch.device("cuda", self._ctx_device if self._ctx_device is not None else torch.cuda.current_device()) if device is None else torch.device(device)
+        if self._ctx is not None:
+            with torch.cuda.device(dev):
+                _check(_lib.bsrnn_sync(self._ctx, _stream_ptr(dev)))
+
     def refresh_weights(self):
-        """Force re-upload (only needed after in-place edits that bypass tensor versioning)."""
+        """Force re-upload (only needed after edits that bypass tensor versioning, e.g. `p.data = other`)."""
         self._pushed_fingerprint = None
+        self._plist = None
 
     @staticmethod
     def _device_for(x):
@@ -303,6 +342,7 @@ class StreamingSeparator:
         h = ctypes.c_void_p()
         _check(_lib.bsrnn_stream_create(ctx, channels, ctypes.byref(h)))
         self._h = h
+        self._steps = 0
 
     def __del__(self):
         try:
@@ -317,11 +357,16 @@ class StreamingSeparator:
         """chunk [C, 1024] float32 (cuda or cpu) -> same-shaped output on the same device."""
         if tuple(chunk.shape) != (self.C, _spec.HOP):
             raise ValueError("expected chunk [%d, 1024], got %s" % (self.C, tuple(chunk.shape)))
+        # the weights of a running stream are looked at every 32nd step only (a parameter edited in place takes effect within 32
+        # chunks; model.refresh_weights() + the next step forces it): the check is host time on a ~0.2 ms step
+        if self._steps % 32 == 0 or self.model._pushed_fingerprint is None:
+            with torch.cuda.device(self.device):
+                self.model._context(self.device)
+        self._steps += 1
         if chunk.is_cuda:
             c = chunk.detach().to(torch.float32).contiguous()
             out = torch.empty_like(c)
             with torch.cuda.device(self.device):
-                self.model._context(self.device)
                 _check(_lib.bsrnn_stream_step(self._h, _ptr(c), _ptr(out), float(mix), _stream_ptr(self.device)))
             return out
         c = np.ascontiguousarray(chunk.detach().numpy(), dtype=np.float32)

@@ -64,6 +64,7 @@ struct bsrnn_ctx {
     // stream on the host (the context has ONE workspace); `gen` counts reallocations of anything a captured streaming
     // graph may point at (workspace, tap buffer, weight arena) so that the graph is re-captured instead of replayed.
     std::atomic<int> busy{0};
+    int range_policy = BSRNN_RANGE_EXACT;      // what a model entry point does about the fp16x2 range guard (bsrnn_set_range_policy)
     unsigned gen = 1;
     int live_streams = 0;           // bsrnn_stream objects that point at this context
     bool zombie = false;            // bsrnn_destroy() was called while streams were alive: freed with the last stream
@@ -85,6 +86,7 @@ struct bsrnn_ctx {
     int job0[NSLOT], njobs[NSLOT], tile0[NSLOT], ntiles[NSLOT], tile_n[NSLOT];
 
     // fused per-band MLP chains (mlp_chain.hip): device descriptor arrays, grouped by class (kernels.h, ChainLaunch)
+    bool stage_error = false;       // run_stage() found no task table for its row count (cannot happen: ensure_tasks runs first); reported by the entry point
     bool small_rows = false;        // the call in flight has <= GEMV_MAX_FRAME_ROWS frame rows: per-layer GEMV launches (gemv.hip)
     bool fused = false;             // false: per-layer launches (BSRNN_MLP=layers, fp32 mode, or a band too wide for the LDS image)
     ChainDesc* d_chain[2] = {nullptr, nullptr};
@@ -95,6 +97,8 @@ struct bsrnn_ctx {
 
     const float *bandW[2][2], *bandB[2][2], *timeW[2], *timeB[2];
     const void *bandW16[2][2], *timeW16[2];
+    const void* timeFc16[2] = {nullptr, nullptr};   // the time blocks' fc as fp16x2 B fragments (fused into the time-axis launch, lstm.hip)
+    const float* timeFcB[2] = {nullptr, nullptr};
     int *h_range = nullptr, *d_range = nullptr;    // range guard of the fp16x2 kernels: host-mapped word the kernels set                     // fp16x2 pieces in MFMA operand order (lstm.hip)
     float* d_tables = nullptr;
     float* d_train_ws = nullptr;       // grow-only scratch of the training entry points (stream-ordered reuse: one call at a time)
@@ -338,30 +342,42 @@ void build_chain_tasks(const bsrnn_ctx* c, int ch, int M, std::vector<int2>& out
         for (int r0 = 0; r0 < M; r0 += chain_rows(ds[di])) out.push_back(make_int2((int)di, r0));
 }
 
-int ensure_tasks(bsrnn_ctx* c, int M)
+// Task tables for the row counts of ONE call (several when the call runs as concurrent row blocks).  The cache is bounded; when it
+// is full it is dropped once, before any of this call's tables is made, so a call never evicts a table it is about to use
+// (captured streaming graphs notice through ctx->gen and re-capture).
+int ensure_tasks(bsrnn_ctx* c, const int* Ms, int n)
 {
     if (!c->fused) return 0;
-    auto it = c->chain_tasks.find(M);
-    if (it == c->chain_tasks.end()) {
-        if (c->chain_tasks.size() >= 64) {           // bounded cache: drop everything (captured streaming graphs re-capture)
-            HIP_TRY(hipDeviceSynchronize());
-            for (auto& kv : c->chain_tasks)
-                for (int ch = 0; ch < 2; ++ch) (void)hipFree(kv.second.d[ch]);
-            c->chain_tasks.clear();
-            ++c->gen;
-        }
+    int missing = 0;
+    for (int i = 0; i < n; ++i) missing += c->chain_tasks.find(Ms[i]) == c->chain_tasks.end();
+    if (!missing) return 0;
+    if (c->chain_tasks.size() + missing > 64) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (auto& kv : c->chain_tasks)
+            for (int ch = 0; ch < 2; ++ch) (void)hipFree(kv.second.d[ch]);
+        c->chain_tasks.clear();
+        ++c->gen;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (c->chain_tasks.find(Ms[i]) != c->chain_tasks.end()) continue;
         bsrnn_ctx::TaskTable t;
+        t.d[0] = t.d[1] = nullptr;
         std::vector<int2> h;
         for (int ch = 0; ch < 2; ++ch) {
-            build_chain_tasks(c, ch, M, h);
+            build_chain_tasks(c, ch, Ms[i], h);
             t.n[ch] = (int)h.size();
-            HIP_TRY(hipMalloc((void**)&t.d[ch], (h.size() + 1) * sizeof(int2)));
-            HIP_TRY(hipMemcpy(t.d[ch], h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice));
+            hipError_t e = hipMalloc((void**)&t.d[ch], (h.size() + 1) * sizeof(int2));
+            if (e == hipSuccess) e = hipMemcpy(t.d[ch], h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                for (int k = 0; k <= ch; ++k) if (t.d[k]) (void)hipFree(t.d[k]);
+                return fail(BSRNN_EHIP, "task table: %s", hipGetErrorString(e));
+            }
         }
-        c->chain_tasks.emplace(M, t);
+        c->chain_tasks.emplace(Ms[i], t);
     }
     return 0;
 }
+int ensure_tasks(bsrnn_ctx* c, int M) { return ensure_tasks(c, &M, 1); }
 
 void gemm_slot(bsrnn_ctx* c, int slot, const float* X, int ldx, float* Y, int ldy, const float* R, int ldr,
                const float* Mul, int ldm, float* tap, int M, int epi, hipStream_t s)
@@ -423,7 +439,9 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         if (c->fused && !force_f32() && !c->small_rows) {      // all five layers of every band in one launch, intermediates in LDS
             ChainLaunch g;
             memset(&g, 0, sizeof g);
-            const bsrnn_ctx::TaskTable& tt = c->chain_tasks.at(M);       // made by ensure_chain_tasks() before any launch (and outside graph capture)
+            auto tti = c->chain_tasks.find(M);                           // made by ensure_tasks() before any launch (and outside graph capture)
+            if (tti == c->chain_tasks.end()) { c->stage_error = true; break; }
+            const bsrnn_ctx::TaskTable& tt = tti->second;
             g.desc = c->d_chain[CHAIN_SPLIT]; g.tasks = tt.d[CHAIN_SPLIT]; g.n_tasks = tt.n[CHAIN_SPLIT];
             g.M = M; g.Xin = p.Xf; g.ldx = c->LDP; g.P = p.P; g.ldp = c->LDP; g.Z = p.Z0; g.ldz = KH; g.range_flag = c->d_range;
             launch_mlp_chain(g, CHAIN_SPLIT, s);
@@ -452,13 +470,17 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     case MS_TIME0: case MS_TIME1: {   // TimewiseLSTM: N = C*K sequences of length T, causal, state carry   bsrnn.py:106-128
         const int blk = stage == MS_TIME1;
         StageScope sc(c, ST_TIME_LSTM, s);
-        launch_time_lstm(p.Z1, p.H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
+        // fp16x2 mode: the launch also computes the block's fc + residual (out = fc(h1) + Z1 -> Z0); otherwise it writes h1
+        const bool fused = time_lstm_fuses_fc();
+        launch_time_lstm(p.Z1, fused ? p.Z0 : p.H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
                          p.state_in ? p.state_in + blk * p.state_slab : nullptr,
-                         p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, c->d_range, s);
+                         p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, c->d_range, s,
+                         c->timeFc16[blk], c->timeFcB[blk]);
         break;
     }
     case MS_TIMEFC0: case MS_TIMEFC1: {
         const int blk = stage == MS_TIMEFC1;
+        if (time_lstm_fuses_fc()) break;          // done inside the time-axis launch
         StageScope sc(c, ST_TIME_FC, s);
         gemm_slot(c, BLK_FC1 + 2 * blk, p.H1, HID, p.Z0, HID, p.Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
         break;
@@ -468,7 +490,9 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         if (c->fused && !force_f32() && !c->small_rows) {
             ChainLaunch g;
             memset(&g, 0, sizeof g);
-            const bsrnn_ctx::TaskTable& tt = c->chain_tasks.at(M);
+            auto tti = c->chain_tasks.find(M);
+            if (tti == c->chain_tasks.end()) { c->stage_error = true; break; }
+            const bsrnn_ctx::TaskTable& tt = tti->second;
             g.desc = c->d_chain[CHAIN_MASK]; g.tasks = tt.d[CHAIN_MASK]; g.n_tasks = tt.n[CHAIN_MASK];
             g.M = M; g.Xin = p.Z0; g.ldx = KH; g.P = p.P; g.ldp = c->LDP; g.Xmul = p.Xf; g.ldm = c->LDP;
             g.Y = p.Yf; g.ldy = c->LDP; g.tap = p.tap; g.ldt = c->LDP; g.range_flag = c->d_range;
@@ -503,6 +527,7 @@ int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T
     p.state_slab = (size_t)2 * 2 * C * c->K * HID;     // one Time block's (h,c) x 2 layers
     for (int st = MS_BANDSPLIT; st <= MS_MASK; ++st) run_stage(c, p, st);
     c->small_rows = false;
+    if (c->stage_error) { c->stage_error = false; return fail(BSRNN_ESTATE, "no task table for %d frame rows (internal error)", C * T); }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -510,10 +535,32 @@ int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T
 int check_range(bsrnn_ctx* c)
 {
     if (c->h_range && *(volatile int*)c->h_range) {
+        const int v = *(volatile int*)c->h_range;
         *(volatile int*)c->h_range = 0;
-        return fail(BSRNN_ERANGE, "an earlier call fed the fp16x2 matrix path an activation beyond +-65504 (or NaN/Inf); its "
-                                  "results are saturated - rescale the input or set BSRNN_GEMM=f32 BSRNN_LSTM=f32");
+        if (v == 3) return fail(BSRNN_EHIP, "an earlier time-axis LSTM launch gave up waiting on its own workgroup-local counters (internal error)");
+        return fail(BSRNN_ERANGE, "an earlier call (range policy 'deferred') fed the fp16x2 matrix path an activation beyond +-65504; its "
+                                  "results are invalid - repeat it under the default policy, rescale the input or set BSRNN_GEMM=f32 BSRNN_LSTM=f32");
     }
+    return 0;
+}
+// End of a model entry point under the default range policy (include/bsrnn_hip.h): wait for the call's own kernels, look at the
+// guard word the fp16x2 kernels set when an operand left the fp16 range, and if it is set run the call again on the library's
+// exact-fp32 kernels (fp32 weights are always resident; no range limit) before returning - never wrong numbers with rc 0.
+template <class F>
+int finish_call(bsrnn_ctx* c, hipStream_t s, F&& rerun)
+{
+    if (c->range_policy != BSRNN_RANGE_EXACT || !c->h_range || force_f32()) return 0;
+    if (gemm_mode() == GEMM_F32 && lstm_mode() == LSTM_F32) return 0;
+    HIP_TRY(hipStreamSynchronize(s));
+    const int v = *(volatile int*)c->h_range;
+    if (!v) return 0;
+    *(volatile int*)c->h_range = 0;
+    if (v == 3) return fail(BSRNN_EHIP, "the time-axis LSTM launch gave up waiting on its own workgroup-local counters (internal error)");
+    set_force_f32(true);
+    const int rc = rerun();
+    set_force_f32(false);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 int check_ready(bsrnn_ctx* c)
@@ -690,6 +737,14 @@ void bsrnn_destroy(bsrnn_ctx* c)
 int bsrnn_n_bands(const bsrnn_ctx* c) { return c ? c->K : -1; }
 int bsrnn_mlp_fused(const bsrnn_ctx* c) { return c ? (c->fused ? 1 : 0) : -1; }
 int bsrnn_device(const bsrnn_ctx* c) { return c ? c->device : -1; }
+int bsrnn_set_range_policy(bsrnn_ctx* c, int32_t policy)
+{
+    if (!c) return fail(BSRNN_EARG, "null context");
+    if (policy != BSRNN_RANGE_EXACT && policy != BSRNN_RANGE_DEFERRED) return fail(BSRNN_EARG, "bsrnn_set_range_policy: unknown policy %d", policy);
+    c->range_policy = policy;
+    return 0;
+}
+int bsrnn_get_range_policy(const bsrnn_ctx* c) { return c ? c->range_policy : -1; }
 int bsrnn_param_count(const bsrnn_ctx* c) { return c ? (int)c->params.size() : -1; }
 
 int bsrnn_param_info(const bsrnn_ctx* c, int32_t i, const char** key, int64_t* d0, int64_t* d1, int32_t* ndim)
@@ -952,7 +1007,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     }
 
     // LSTM weights, folded and packed in the kernels' register order (lstm.hip)
-    size_t o_bandW[2][2], o_bandW16[2][2], o_bandB[2][2], o_timeW[2], o_timeW16[2], o_timeB[2];
+    size_t o_bandW[2][2], o_bandW16[2][2], o_bandB[2][2], o_timeW[2], o_timeW16[2], o_timeB[2], o_timeFc16[2], o_timeFcB[2];
     std::vector<double> wcat, bsum;
     for (int blk = 0; blk < 2; ++blk) {
         const int jb_ = 2 * blk;                               // lstms.0 / lstms.2: bidirectional over bands
@@ -1021,6 +1076,25 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         o_timeW[blk] = ar.put(pk);
         o_timeW16[blk] = ar.put(reinterpret_cast<const float*>(pk16.data()), pk16.size() / 2);
         o_timeB[blk] = ar.put(pb);
+        {   // the block's fc (64 -> 64, bsrnn.py:84) in the f16 MFMA's B-operand order: [4 wave][2 blk][2 piece][64 lane][8],
+            // lane (n = l & 15, kb = l >> 4) holds W_fc[16 wave + n][32 blk + 8 kb .. + 7]
+            snprintf(b, sizeof b, "lstms.%d.m.fc.weight", jt); const Param& wfc = P_(c, b);
+            snprintf(b, sizeof b, "lstms.%d.m.fc.bias", jt); const Param& bfc = P_(c, b);
+            std::vector<uint16_t> f16((size_t)4 * 2 * 2 * 64 * 8);
+            for (int wv = 0; wv < 4; ++wv)
+                for (int bk = 0; bk < 2; ++bk)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = wfc.data[(size_t)(16 * wv + (ln & 15)) * H + 32 * bk + 8 * (ln >> 4) + e];
+                            uint16_t pc[2];
+                            split_planes_host(&v, 1, 2, pc);
+                            const size_t base = ((size_t)wv * 2 + bk) * 2;
+                            f16[((base + 0) * 64 + ln) * 8 + e] = pc[0];
+                            f16[((base + 1) * 64 + ln) * 8 + e] = pc[1];
+                        }
+            o_timeFc16[blk] = ar.put(reinterpret_cast<const float*>(f16.data()), f16.size() / 2);
+            o_timeFcB[blk] = ar.put(bfc.data);
+        }
     }
 
     // upload
@@ -1063,6 +1137,8 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         c->timeW[blk] = c->d_arena + o_timeW[blk];
         c->timeW16[blk] = c->d_arena + o_timeW16[blk];
         c->timeB[blk] = c->d_arena + o_timeB[blk];
+        c->timeFc16[blk] = c->d_arena + o_timeFc16[blk];
+        c->timeFcB[blk] = c->d_arena + o_timeFcB[blk];
     }
     c->committed = true;
     return 0;
@@ -1141,15 +1217,19 @@ int bsrnn_forward(bsrnn_ctx* c, const float* x, float* y, float* mask, int32_t C
     const size_t M = (size_t)C * T;
     if ((rc = ensure_ws(c, M)) || (rc = ensure_tasks(c, (int)M))) return rc;
     if (mask && (rc = ensure_tap(c, M))) return rc;
-    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, T, s); }
-    if ((rc = run_model(c, c->Xf, c->Yf, mask ? c->d_tap : nullptr, C, T, nullptr, nullptr, s))) return rc;
-    {
-        StageScope sc(c, ST_LAYOUT, s);
-        launch_from_frame_major(c->tb, c->Yf, y, C, T, s);
-        if (mask) launch_from_frame_major(c->tb, c->d_tap, mask, C, T, s);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    auto run = [&]() -> int {
+        { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, T, s); }
+        if (int rc2 = run_model(c, c->Xf, c->Yf, mask ? c->d_tap : nullptr, C, T, nullptr, nullptr, s)) return rc2;
+        {
+            StageScope sc(c, ST_LAYOUT, s);
+            launch_from_frame_major(c->tb, c->Yf, y, C, T, s);
+            if (mask) launch_from_frame_major(c->tb, c->d_tap, mask, C, T, s);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if ((rc = run())) return rc;
+    return finish_call(c, s, run);
 }
 
 int bsrnn_forward_chunk(bsrnn_ctx* c, const float* x, const float* state_in, float* y, float* state_out,
@@ -1162,11 +1242,17 @@ int bsrnn_forward_chunk(bsrnn_ctx* c, const float* x, const float* state_in, flo
     ENTER_CALL(c, s);
     const size_t M = (size_t)C * L;
     if ((rc = ensure_ws(c, M)) || (rc = ensure_tasks(c, (int)M))) return rc;
-    { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, L, s); }
-    if ((rc = run_model(c, c->Xf, c->Yf, nullptr, C, L, state_in, state_out, s))) return rc;
-    { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->tb, c->Yf, y, C, L, s); }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    if (state_in == state_out && c->range_policy == BSRNN_RANGE_EXACT)
+        return fail(BSRNN_EARG, "bsrnn_forward_chunk: state_in and state_out must be different buffers (a call that leaves the fp16 range is run again from state_in)");
+    auto run = [&]() -> int {
+        { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, L, s); }
+        if (int rc2 = run_model(c, c->Xf, c->Yf, nullptr, C, L, state_in, state_out, s)) return rc2;
+        { StageScope sc(c, ST_LAYOUT, s); launch_from_frame_major(c->tb, c->Yf, y, C, L, s); }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if ((rc = run())) return rc;
+    return finish_call(c, s, run);
 }
 
 int bsrnn_forward_recurrent(bsrnn_ctx* c, const float* x, const float* state_in, float* y, float* state_out,
@@ -1186,19 +1272,26 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
     const int M = C * T, K = c->K;
     if ((rc = ensure_ws(c, M))) return rc;
     const size_t nz = (size_t)M * K * HID;
+    if (state_in && state_in == state_out && c->range_policy == BSRNN_RANGE_EXACT)
+        return fail(BSRNN_EARG, "bsrnn_dual_path: state_in and state_out must be different buffers");
+    auto run = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(c->Z0, z, nz * sizeof(float), hipMemcpyDeviceToDevice, s));
     const size_t slab = (size_t)2 * 2 * C * K * HID;
     for (int blk = 0; blk < 2; ++blk) {
         launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
         launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);
         gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
-        launch_time_lstm(c->Z1, c->H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
-                         state_out ? state_out + blk * slab : nullptr, C, T, K, c->d_range, s);
-        gemm_slot(c, BLK_FC1 + 2 * blk, c->H1, HID, c->Z0, HID, c->Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+        const bool fused = time_lstm_fuses_fc();
+        launch_time_lstm(c->Z1, fused ? c->Z0 : c->H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
+                         state_out ? state_out + blk * slab : nullptr, C, T, K, c->d_range, s, c->timeFc16[blk], c->timeFcB[blk]);
+        if (!fused) gemm_slot(c, BLK_FC1 + 2 * blk, c->H1, HID, c->Z0, HID, c->Z1, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
     }
     HIP_TRY(hipMemcpyAsync(z_out, c->Z0, nz * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     return 0;
+    };
+    if ((rc = run())) return rc;
+    return finish_call(c, s, run);
 }
 
 // --------------------------------------------------------------------------- training step, part 1: recurrent layers
@@ -1223,6 +1316,7 @@ static int train_args_ok(bsrnn_ctx* c, int32_t N, int32_t L, int32_t IN, int32_t
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    HIP_TRY(hipSetDevice(c->device));
     if (N < 1 || L < 1 || (IN != HID && IN != 2 * HID) || ndir < 1 || ndir > 2 || (int64_t)N * L > (int64_t)1 << 30)
         return fail(BSRNN_EARG, "%s: need N, L >= 1, IN = 64 | 128, ndir = 1 | 2 (got N=%d L=%d IN=%d ndir=%d)", who, N, L, IN, ndir);
     return 0;
@@ -1265,6 +1359,7 @@ int bsrnn_adamw_step(bsrnn_ctx* c, float* p, const float* g, float* m, float* v,
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    HIP_TRY(hipSetDevice(c->device));
     if (!p || !g || !m || !v || n < 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
         return fail(BSRNN_EARG, "bsrnn_adamw_step: bad arguments (n=%lld step=%d)", (long long)n, step);
     hipStream_t s = (hipStream_t)stream;
@@ -1280,6 +1375,7 @@ int bsrnn_adamw_step_multi(bsrnn_ctx* c, float* const* p, const float* const* g,
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    HIP_TRY(hipSetDevice(c->device));
     if (!p || !g || !m || !v || !sizes || n_tensors < 1 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
         return fail(BSRNN_EARG, "bsrnn_adamw_step_multi: bad arguments (n_tensors=%d step=%d)", n_tensors, step);
     for (int i = 0; i < n_tensors; ++i)
@@ -1309,6 +1405,7 @@ int bsrnn_linear_train_forward(bsrnn_ctx* c, const float* x, int32_t ldx, const 
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    HIP_TRY(hipSetDevice(c->device));
     if (!x || !w || !b || !y || M < 1 || K < 1 || N < 1 || ldx < K || ldy < N)
         return fail(BSRNN_EARG, "bsrnn_linear_train_forward: bad arguments (M=%d K=%d N=%d ldx=%d ldy=%d)", M, K, N, ldx, ldy);
     hipStream_t s = (hipStream_t)stream;
@@ -1324,6 +1421,7 @@ int bsrnn_linear_train_backward(bsrnn_ctx* c, const float* x, int32_t ldx, const
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    HIP_TRY(hipSetDevice(c->device));
     if (!x || !w || !dy || !dw || !db || (leaky && !y) || M < 1 || K < 1 || N < 1 || ldx < K || lddy < N || (leaky && ldy < N) || (dx && lddx < K))
         return fail(BSRNN_EARG, "bsrnn_linear_train_backward: bad arguments (M=%d K=%d N=%d)", M, K, N);
     hipStream_t s = (hipStream_t)stream;
@@ -1343,6 +1441,7 @@ int bsrnn_linear_group_train_forward(bsrnn_ctx* c, int32_t n, const float* const
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    HIP_TRY(hipSetDevice(c->device));
     if (n < 1 || n > 4096 || !x || !ldx || !w || !b || !y || !ldy || !K || !N || M < 1) return fail(BSRNN_EARG, "bsrnn_linear_group_train_forward: bad arguments");
     std::vector<LinearJob> jobs((size_t)n);
     for (int i = 0; i < n; ++i) {
@@ -1366,6 +1465,7 @@ int bsrnn_linear_group_train_backward(bsrnn_ctx* c, int32_t n, const float* cons
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
+    HIP_TRY(hipSetDevice(c->device));
     if (n < 1 || n > 4096 || !x || !ldx || !w || !dy || !lddy || !dx || !lddx || !dw || !db || !K || !N || M < 1 || (leaky && (!y || !ldy)))
         return fail(BSRNN_EARG, "bsrnn_linear_group_train_backward: bad arguments");
     std::vector<LinearJob> jobs((size_t)n);
@@ -1462,30 +1562,39 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
     if (R < 2 * parts || (int64_t)R * T < 2048) parts = 1;
     if (parts > 1 && (rc = ensure_streams(c, parts))) return rc;
     Part pt[MAX_PARTS];
+    {   // task tables of every row block of this call, made before any launch: one call never evicts a table it needs itself
+        int ms[MAX_PARTS];
+        for (int j = 0; j < parts; ++j) ms[j] = ((int)((int64_t)R * (j + 1) / parts) - (int)((int64_t)R * j / parts)) * T;
+        if ((rc = ensure_tasks(c, ms, parts))) return rc;
+    }
     for (int j = 0; j < parts; ++j) {
         const int r0 = (int)((int64_t)R * j / parts), r1 = (int)((int64_t)R * (j + 1) / parts);
         pt[j] = make_part(c, r0, r1 - r0, T, parts > 1 ? c->aux[j] : s);
-        if ((rc = ensure_tasks(c, (r1 - r0) * T))) return rc;
         pt[j].wave = wave + (size_t)r0 * n; pt[j].n = n;
         pt[j].wave_out = wave_out + (size_t)r0 * out_len;
     }
-    if (parts > 1) {
-        HIP_TRY(hipEventRecord(c->ev_fork, s));
-        for (int j = 0; j < parts; ++j) HIP_TRY(hipStreamWaitEvent(c->aux[j], c->ev_fork, 0));
-    }
-    const int lag = c->part_lag;
-    for (int step = 0; step < MS_COUNT + lag * (parts - 1); ++step)
-        for (int j = 0; j < parts; ++j) {
-            const int st = step - lag * j;
-            if (st >= 0 && st < MS_COUNT) run_stage(c, pt[j], st);
+    auto run = [&]() -> int {
+        if (parts > 1) {
+            HIP_TRY(hipEventRecord(c->ev_fork, s));
+            for (int j = 0; j < parts; ++j) HIP_TRY(hipStreamWaitEvent(c->aux[j], c->ev_fork, 0));
         }
-    if (parts > 1)
-        for (int j = 0; j < parts; ++j) {
-            HIP_TRY(hipEventRecord(c->ev_join[j], c->aux[j]));
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_join[j], 0));
-        }
-    HIP_TRY(hipGetLastError());
-    return 0;
+        const int lag = c->part_lag;
+        for (int step = 0; step < MS_COUNT + lag * (parts - 1); ++step)
+            for (int j = 0; j < parts; ++j) {
+                const int st = step - lag * j;
+                if (st >= 0 && st < MS_COUNT) run_stage(c, pt[j], st);
+            }
+        if (parts > 1)
+            for (int j = 0; j < parts; ++j) {
+                HIP_TRY(hipEventRecord(c->ev_join[j], c->aux[j]));
+                HIP_TRY(hipStreamWaitEvent(s, c->ev_join[j], 0));
+            }
+        if (c->stage_error) { c->stage_error = false; return fail(BSRNN_ESTATE, "no task table for a row block of this call (internal error)"); }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    if ((rc = run())) return rc;
+    return finish_call(c, s, run);
 }
 
 // --------------------------------------------------------------------------- validation metrics
@@ -1677,17 +1786,11 @@ static void stream_drop_graph(bsrnn_stream* st)
     if (st->graph) { (void)hipGraphDestroy(st->graph); st->graph = nullptr; }
 }
 
-int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mix, void* stream)
+// one step on the stream object's own buffers (st->chunk -> st->out), by graph replay when possible
+static int stream_step_run(bsrnn_stream* st, float mix, hipStream_t s)
 {
-    if (!st || !chunk || !out) return fail(BSRNN_EARG, "bsrnn_stream_step: null argument");
     bsrnn_ctx* c = st->ctx;
-    int rc = check_ready(c);
-    if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    ENTER_CALL(c, s);
-    if ((rc = ensure_ws(c, st->C)) || (rc = ensure_tasks(c, st->C))) return rc;
-    const size_t nb = (size_t)st->C * HOPS * sizeof(float);
-    if (chunk != st->chunk) HIP_TRY(hipMemcpyAsync(st->chunk, chunk, nb, hipMemcpyDeviceToDevice, s));
+    int rc;
     int mix_bits;
     memcpy(&mix_bits, &mix, sizeof mix_bits);
     if (!st->mix_set || st->mix_bits != mix_bits || st->mix_stream != s) {      // the control rarely changes: no fill launch per chunk
@@ -1716,6 +1819,31 @@ int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mi
     } else if ((rc = stream_step_launches(st, s))) {
         return rc;
     }
+    return 0;
+}
+
+int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mix, void* stream)
+{
+    if (!st || !chunk || !out) return fail(BSRNN_EARG, "bsrnn_stream_step: null argument");
+    bsrnn_ctx* c = st->ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    ENTER_CALL(c, s);
+    if ((rc = ensure_ws(c, st->C)) || (rc = ensure_tasks(c, st->C))) return rc;
+    const size_t nb = (size_t)st->C * HOPS * sizeof(float);
+    if (chunk != st->chunk) HIP_TRY(hipMemcpyAsync(st->chunk, chunk, nb, hipMemcpyDeviceToDevice, s));
+    // default range policy in a split-precision mode: keep what the step is about to overwrite (analysis buffer, previous
+    // synthesis frame, LSTM state), so that a step whose operands leave the fp16 range can be run again, exactly, from the
+    // same starting point (finish_call)
+    const bool guarded = c->range_policy == BSRNN_RANGE_EXACT && c->h_range && !force_f32() && (gemm_mode() != GEMM_F32 || lstm_mode() != LSTM_F32);
+    if (guarded) HIP_TRY(hipMemcpyAsync(st->shadow, st->buf, st->carry_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if ((rc = stream_step_run(st, mix, s))) return rc;
+    if ((rc = finish_call(c, s, [&]() -> int {
+            HIP_TRY(hipMemcpyAsync(st->buf, st->shadow, st->carry_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+            return stream_step_run(st, mix, s);
+        })))
+        return rc;
     if (out != st->out) HIP_TRY(hipMemcpyAsync(out, st->out, nb, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1731,24 +1859,14 @@ int bsrnn_stream_step_host(bsrnn_stream* st, const float* chunk_host, float* out
     const size_t nb = (size_t)st->C * HOPS * sizeof(float);
     memcpy(st->h_in, chunk_host, nb);
     HIP_TRY(hipMemcpyAsync(st->chunk, st->h_in, nb, hipMemcpyHostToDevice, nullptr));
-    // split-precision modes: keep what the step is about to overwrite (analysis buffer, previous synthesis frame, LSTM
-    // state), so that a step whose operands leave the fp16 range can be run again, exactly, from the same starting point
-    const bool guarded = c->h_range && (gemm_mode() != GEMM_F32 || lstm_mode() != LSTM_F32);
-    if (guarded) HIP_TRY(hipMemcpyAsync(st->shadow, st->buf, st->carry_floats * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
-    if ((rc = bsrnn_stream_step(st, st->chunk, st->out, mix, nullptr))) return rc;
+    // This entry point waits for its own kernels anyway, so it repairs a range violation whatever the policy says
+    const int keep = c->range_policy;
+    c->range_policy = BSRNN_RANGE_EXACT;
+    rc = bsrnn_stream_step(st, st->chunk, st->out, mix, nullptr);
+    c->range_policy = keep;
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(st->h_out, st->out, nb, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    if (guarded && *(volatile int*)c->h_range) {
-        // synchronous call: the guard is final.  Re-run this step on the exact-fp32 kernels of the library (no range limit).
-        *(volatile int*)c->h_range = 0;
-        HIP_TRY(hipMemcpyAsync(st->buf, st->shadow, st->carry_floats * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
-        set_force_f32(true);
-        rc = bsrnn_stream_step(st, st->chunk, st->out, mix, nullptr);
-        set_force_f32(false);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(st->h_out, st->out, nb, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipStreamSynchronize(nullptr));
-    }
     memcpy(out_host, st->h_out, nb);
     return 0;
 }

@@ -131,8 +131,13 @@ int lstm_mode();
 //   zin/hout [R][T][K][64]; sequences n = r*K + k;  wpk packed [2 layer][4 wave][128 k][64 lane]
 //   state_in/out [2 (h,c)][2 layer][R*K][64] or null
 //   wpk16 (LSTM_FP16X2): two fp16 pieces in B-operand order, [2 layer][4 wave][4 blk][4 gate][2 piece][64 lane][8]
+//   fc16 / fcb (LSTM_FP16X2, optional): the block's trailing fc (bsrnn.py:84) as two fp16 pieces in B-operand order,
+//         [4 wave][2 blk][2 piece][64 lane][8], and its bias [64].  When time_lstm_fuses_fc() and both are given, the launch
+//         writes the BLOCK's output fc(h1) + b + zin to hout (h1 never leaves the chip); otherwise hout = h1.
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream);
+                      const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,
+                      const void* fc16 = nullptr, const float* fcb = nullptr);
+bool time_lstm_fuses_fc();
 
 // ------------------------------------------------------------------ training step, part 1: recurrent layers (lstm_train.hip)
 // One nn.LSTM layer (bsrnn.py:66-72) with ndir directions over N sequences of L steps, exact fp32; weights in torch layout

@@ -296,9 +296,8 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     amax = __builtin_fmaxf(amax, __builtin_fabsf(v[e]));
-                    const float cl = __builtin_fminf(__builtin_fmaxf(v[e], -65504.f), 65504.f);
                     _Float16 a, b2;
-                    split_h2(cl, a, b2);
+                    split_h2(v[e], a, b2);                 // (no clamp, as in gemm.hip / mlp_chain.hip: the guard reports it)
                     p0[e] = a; p1[e] = b2;
                 }
                 const int o = ((xcol[i] >> 1) * 16 + xrow[i]) * 8 + (xcol[i] & 1) * 4;
@@ -715,7 +714,7 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
         for (int e = 0; e < 4; ++e) {
             amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
             _Float16 a, b2;
-            split_h2(__builtin_fminf(__builtin_fmaxf(f[e], -65504.f), 65504.f), a, b2);
+            split_h2(f[e], a, b2);
             p0[e] = a; p1[e] = b2;
         }
         _Float16* dst = &xpl[((chunk & 1) * TCH + xs_t) * TSTEP + ((xs_c4 >> 1) * 4 + xs_i) * 8 + (xs_c4 & 1) * 4];
@@ -848,15 +847,418 @@ __global__ __launch_bounds__(512) void time_lstm_h2_kernel(const float* __restri
     }
 }
 
+// =====================================================================================
+// Time-axis LSTM, split precision, SIXTEEN waves per workgroup and NO per-step workgroup barrier (round 3; the kernel
+// the fp16x2 mode launches).  Same decomposition and the same arithmetic as time_lstm_h2_kernel above (4 sequences per
+// workgroup, one cell per lane, recurrent half with the second piece on row 4j + 1, input half of four steps batched into
+// one 16-row tile) - h1 and the carried state are bit-identical to it - but the work is spread over four roles of four
+// waves each, one wave of every role on every SIMD:
+//     M0, M1  "main" waves of layer 0 / layer 1: ONLY the serial chain of a step - h_{t-1} fragments from LDS, 16
+//             recurrent MFMAs against the resident W_hh, the cell, h_t to LDS.  W_hh alone is 64 VGPRs, so a main wave fits
+//             the 128 registers of a 1024-thread workgroup.
+//     H0, H1  "helper" waves: everything that is NOT on that chain - the batched input half (x W_ih / h0 W_ih of a group of
+//             four steps, bias + result to an LDS buffer the main wave reads), the staging of x (global -> fp16 pieces ->
+//             LDS), and for layer 1 the block's trailing fc + residual (FUSE, below).
+// What was measured on the way (profiles/r03_time_lstm.txt): in the 8-wave kernels every wave's own instruction stream WAS
+// the step (a lone wave issues one instruction per 4-6 clocks: ~200 instructions = 0.75 us per step, whether the two layers
+// ran their phases in lockstep or in counter-phase); with the roles above but one s_barrier per step the step was still
+// 0.71 us, because a barrier makes every step as long as its slowest role and the helpers' MFMAs queue behind the main
+// waves'.  So the roles are decoupled: the only synchronisation inside the launch are monotonic counters in LDS
+// (sync[]: steps completed per layer, groups published per layer, ...), added to by lane 0 of a wave behind its LDS
+// writes (one wave's LDS operations execute in order) and polled with ds_read by whoever needs the data.  The two layers'
+// chains then run at their own pace and fill each other's gaps on the shared matrix pipe and vector issue; layer 1 trails
+// layer 0 by what the data dependences require (its group's h0 must be complete before its input half can be batched).
+// Rings in LDS: h0 and h1 16 steps each, x 2 chunks of 8 steps, input-half buffers 2 groups per layer; every overwrite
+// waits on the counter that says its last reader is done.
+// FUSE: the block's fc + residual (NormRNNResidual, bsrnn.py:84-86: out = fc(h1) + x) is computed by H1, batched over the
+// four steps of a group like the input half (6 MFMAs per group and wave, wave w = output features 16 w .. 16 w + 15): h1
+// never goes to HBM and the separate grouped-GEMM launch (15 us, 75 MB per block) is gone; `hout` is then the block's output.
+// =====================================================================================
+#ifndef TIME_ABL
+#define TIME_ABL 0                // measurement only (tools/time_lstm_v3_bench.hip): 1 main waves do not wait for the input half, 2 helpers issue no MFMAs, 4 main waves do not wait for h(t-1), 8 no helper work at all
+#endif
+#ifndef TIME_OPT
+#define TIME_OPT 3                // 1: main waves at raised priority; 2: h(t-1) fragments requested together with the poll of the step counter
+#endif
+constexpr int H0RING = 16, H1RING = 16;        // steps of h0 / h1 kept in LDS
+enum { SY_DONE0 = 0, SY_DONE1, SY_PIN0, SY_PIN1, SY_FC, SY_X, SY_ABORT, SY_COUNT = 8 };
+constexpr int SPIN_LIMIT = 1 << 21;            // polls of one wait before the workgroup gives up (seconds; a step takes ~10 polls)
+
+// spin until the LDS counter has reached `target` (monotonic; every wave that waits is in the same workgroup as the waves
+// that add, so all of them are resident).  The memory clobbers keep the compiler from moving LDS accesses across the wait.
+// Every spin is bounded: a wait that never ends (it cannot, by construction) sets the abort word, which ends every other
+// wait of the workgroup as well, and the launch reports it through the range-guard word (value 3) instead of hanging.
+// (the poll is an explicit ds_read_b32: through a volatile generic pointer hipcc emitted a FLAT load with sc0 sc1 and a wait for
+// vmcnt(0), i.e. for every global load and store the wave had in flight)
+__device__ __forceinline__ int lds_peek(const int* p)
+{
+    int v;
+    const unsigned a = (unsigned)(size_t)p;      // low half of the generic address of a __shared__ object = its LDS byte address
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void lds_wait_ge(int* sync, int which, int target)
+{
+    int spins = 0;
+    while (lds_peek(&sync[which]) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SPIN_LIMIT) __hip_atomic_store(&sync[SY_ABORT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (spins > 64 && lds_peek(&sync[SY_ABORT])) break;
+    }
+}
+// one arrival of this wave: behind everything the wave has written to LDS so far
+__device__ __forceinline__ void lds_arrive(int* cnt, int lane)
+{
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+
+template <bool FUSE, bool TRACE = false>
+__global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __restrict__ zin, float* __restrict__ hout,
+                                                             const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                             const uint4* __restrict__ wfc, const float* __restrict__ bfc,
+                                                             const float* __restrict__ state_in, float* __restrict__ state_out,
+                                                             int R, int T, int K, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg)
+{
+    unsigned long long tp[4] = {0, 0, 0, 0}, tq = 0;          // measurement only
+    auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[2 * TCH * TSTEP];     // [chunk slot][step in chunk]
+    __shared__ __attribute__((aligned(16))) _Float16 h0pl[H0RING * TSTEP];     // h0_t in slot t & 15
+    __shared__ __attribute__((aligned(16))) _Float16 h1pl[H1RING * TSTEP];     // h1_t in slot t & 15
+    __shared__ __attribute__((aligned(16))) float pinb[2 * 2 * 4 * 4 * 256];   // [layer][group parity][step in group][gate][cell]: bias + input half
+    __shared__ __attribute__((aligned(16))) uint4 wflds[FUSE ? 4 * 4 * 64 : 1];
+    __shared__ int sync[SY_COUNT];            // the counters (and the abort word) of lds_wait_ge / lds_arrive
+
+    const int N = R * K;
+    const int n0 = blockIdx.x * 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                 // wave-uniform: the roles below are scalar branches
+    const int role = wave >> 2, w4 = wave & 3;
+    const int layer = role & 1;
+    const int n = lane & 15, q = lane >> 4;
+    const int unit = 16 * w4 + n;
+    const int cellid = w4 * 64 + lane;
+    const size_t tstride = (size_t)K * HID;
+    const int G = (T + 3) >> 2;                  // groups of four steps
+
+    // this lane's cell: (unit, sequence q)
+    const int nq_raw = n0 + q;
+    const int nq = nq_raw < N ? nq_raw : N - 1;
+    const size_t base_q = ((size_t)(nq / K) * T * K + (nq % K)) * HID;
+    const int afrag = (q * 4 + (n >> 2)) * 8;    // A fragment inside a 32-deep block of a piece: row l & 15 = (sequence (l & 15) >> 2, ...)
+    const int bstep = n & 3;                     // ... batched form: step (l & 15) & 3 of the group
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (tid < SY_COUNT) sync[tid] = 0;
+    if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
+
+    if (role < 2) {
+        // ------------------------------------------------------------------ main waves: the serial chain
+        h8v w[2][4][2];                           // W_hh: [k block][gate][piece]
+        {
+            const uint4* wp = wpk + ((size_t)(layer * 4 + w4) * 4 * 4 * 2) * 64 + lane;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[(((2 + b) * 4 + gte) * 2 + pc) * 64]);
+        }
+        const int hoff = ((unit >> 3) * 4 + q) * 8 + (unit & 7);      // where this lane's h goes inside a piece
+        _Float16* const ring = layer ? h1pl : h0pl;
+        const int rmask = layer ? H1RING - 1 : H0RING - 1;
+        float c = state_in ? state_in[((size_t)(2 + layer) * N + nq) * HID + unit] : 0.f;
+        {
+            const float hinit = state_in ? state_in[((size_t)layer * N + nq) * HID + unit] : 0.f;
+            _Float16 p0, p1;
+            split_h2(hinit, p0, p1);
+            _Float16* hb = &ring[rmask * TSTEP];                      // h_{-1}
+            hb[hoff] = p0;
+            hb[4 * HID + hoff] = p1;
+        }
+        float hsel = 0.f, csel = 0.f;
+        // Only rows 4j of the 16-row tile carry a sequence, so row 4j + 1 is given the SECOND piece of the same sequence: one
+        // MFMA against w1 yields a1 w1 in register 0 and a2 w1 in register 1 of the owning lane, a second one against w2
+        // yields a1 w2 in register 0 - two MFMAs per (block, gate) instead of three, one fragment read per block.
+        const int rfrag = afrag + ((n & 3) == 1 ? 4 * HID : 0);
+        const float* const pin_l = pinb + layer * 8192 + cellid;
+        const int my_done = layer ? SY_DONE1 : SY_DONE0, my_pin = layer ? SY_PIN1 : SY_PIN0;
+        // whoever reads this layer's ring besides the layer itself: H1 batches h0 and (fc) h1
+        const int reader = layer ? SY_FC : SY_PIN1;
+        const bool has_reader = layer ? FUSE : true;
+        const int rsteps = layer ? H1RING : H0RING;
+        __syncthreads();                          // h_{-1}, counters, x chunk 0 (the helpers publish group 0 behind it)
+        if (TIME_OPT & 1) __builtin_amdgcn_s_setprio(2);     // the chain before the helpers wherever both could issue
+        for (int t = 0; t < T; ++t) {
+            if ((t & 3) == 0) {
+                if (!(TIME_ABL & 1)) lds_wait_ge(sync, my_pin, 4 * ((t >> 2) + 1));              // this group's input half is published
+                if (has_reader && t >= rsteps) lds_wait_ge(sync, reader, 4 * (((t - rsteps) >> 2) + 1));   // the slots this group overwrites have been read
+            }
+            stamp(3);
+            const _Float16* src = &ring[((t - 1) & rmask) * TSTEP];
+            h8v a[2];
+            if (TIME_OPT & 2) {
+                // h_{t-1} complete (all four waves)?  The counter and the two fragments are requested together - LDS operations of a
+                // wave execute in order, so fragments that follow a counter value >= 4 t are complete - and requested again if not:
+                // one LDS round trip per step instead of two.
+                const unsigned ca = (unsigned)(size_t)&sync[my_done], fa = (unsigned)(size_t)&src[rfrag];
+                int spins = 0;
+                for (;;) {
+                    int cv;
+                    u4v f0, f1;
+                    asm volatile("ds_read_b32 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(cv), "=&v"(f0), "=&v"(f1) : "v"(ca), "v"(fa) : "memory");
+                    a[0] = __builtin_bit_cast(h8v, f0); a[1] = __builtin_bit_cast(h8v, f1);
+                    if ((TIME_ABL & 4) || __builtin_amdgcn_readfirstlane(cv) >= 4 * t) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT) __hip_atomic_store(&sync[SY_ABORT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (spins > 64 && lds_peek(&sync[SY_ABORT])) break;
+                }
+            } else {
+                if (!(TIME_ABL & 4)) lds_wait_ge(sync, my_done, 4 * t);                          // h_{t-1} complete (all four waves)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) a[b] = *reinterpret_cast<const h8v*>(&src[b * 128 + rfrag]);
+            }
+            stamp(2);
+            const float* const pin_t = pin_l + (((t >> 2) & 1) * 4 + (t & 3)) * 1024;
+            const float pin_i = pin_t[0], pin_f = pin_t[256], pin_g = pin_t[512], pin_o = pin_t[768];
+            v4f hi[4], lo[4];
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) { hi[gte] = zero4; lo[gte] = zero4; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[b], w[b][gte][0], hi[gte], 0, 0, 0);
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[b], w[b][gte][1], lo[gte], 0, 0, 0);
+            }
+            // hi[g] = {a1 w1, a2 w1, -, -}, lo[g] = {a1 w2, -, -, -} of this lane's cell
+            const float ig = fast_sigmoid(pin_i + (hi[0][0] + (hi[0][1] + lo[0][0]) * (1.f / 2048.f)));
+            const float fg = fast_sigmoid(pin_f + (hi[1][0] + (hi[1][1] + lo[1][0]) * (1.f / 2048.f)));
+            const float gg = fast_tanh(pin_g + (hi[2][0] + (hi[2][1] + lo[2][0]) * (1.f / 2048.f)));
+            const float og = fast_sigmoid(pin_o + (hi[3][0] + (hi[3][1] + lo[3][0]) * (1.f / 2048.f)));
+            c = fg * c + ig * gg;
+            hsel = og * fast_tanh(c);
+            csel = c;
+            _Float16 p0, p1;
+            split_h2(hsel, p0, p1);
+            _Float16* hb = &ring[(t & rmask) * TSTEP];
+            hb[hoff] = p0;
+            hb[4 * HID + hoff] = p1;
+            lds_arrive(&sync[my_done], lane);
+            if (!FUSE && layer && nq_raw < N) hout[base_q + (size_t)t * tstride + unit] = hsel;
+            stamp(0);
+        }
+        if (state_out && nq_raw < N) {
+            state_out[((size_t)layer * N + nq) * HID + unit] = hsel;           // h_{T-1}
+            state_out[((size_t)(2 + layer) * N + nq) * HID + unit] = csel;     // c_{T-1}
+        }
+    } else {
+        // ------------------------------------------------------------------ helper waves: input halves, x staging, fc
+        h8v w[2][4][2];                           // W_ih (fc_in folded for layer 0): [k block][gate][piece]
+        {
+            const uint4* wp = wpk + ((size_t)(layer * 4 + w4) * 4 * 4 * 2) * 64 + lane;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[((b * 4 + gte) * 2 + pc) * 64]);
+        }
+        float bs[4];
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[layer * 256 + gte * 64 + unit];
+        float bf = 0.f;
+        if (FUSE && layer) {                      // the fc matrix as B fragments [k block][piece] (column = output feature `unit`): used once per
+            const uint4* wp = wfc + ((size_t)w4 * 2 * 2) * 64 + lane;       // group, so it lives in LDS; a wave reads back what it wrote itself
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wflds[(w4 * 4 + i) * 64 + lane] = wp[i * 64];
+            bf = bfc[unit];
+        }
+        // input half of the four steps of `group` (A rows = (sequence, step), `src` = slot of the group's first step): per gate
+        // 6 MFMAs, then bias + result to the LDS buffer the main wave of this cell reads, [step][gate][cell]
+        auto input_half = [&](const _Float16* src, int group) {
+            if (TIME_ABL & 8) return;
+            const _Float16* mine = src + bstep * TSTEP;
+            h8v a0[2], a1[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                a0[b] = *reinterpret_cast<const h8v*>(&mine[b * 128 + afrag]);
+                a1[b] = *reinterpret_cast<const h8v*>(&mine[4 * HID + b * 128 + afrag]);
+            }
+            float* dst = pinb + layer * 8192 + (group & 1) * 4096 + cellid;
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) {
+                v4f ghi = zero4, glo = zero4;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (TIME_ABL & 2) { ghi[0] += (float)a0[b][0] * (float)w[b][gte][0][0]; glo[1] += (float)a1[b][1] * (float)w[b][gte][1][1]; continue; }
+                    ghi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][0], ghi, 0, 0, 0);
+                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][1], glo, 0, 0, 0);
+                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[b], w[b][gte][0], glo, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e * 1024 + gte * 256] = bs[gte] + (ghi[e] + glo[e] * (1.f / 2048.f));
+            }
+        };
+        if (!layer) {
+            // ---------------- H0: x staging (its 256 threads: 8 steps x 4 sequences x 16 float4 = 512 float4, two per thread) and
+            // the input half of layer 0.  Chunk c (steps 8 c ...) lives in slot c & 1; it is requested a whole chunk ahead,
+            // stored once every H0 wave has published the groups that read the slot's previous content, and read once every
+            // H0 wave has stored its share.
+            const int xs_t = cellid >> 6, xs_i = (cellid >> 4) & 3, xs_c4 = cellid & 15;      // thread -> (step 0-3 [+4], sequence, float4)
+            size_t xs_base;
+            {
+                int ni = n0 + xs_i; ni = ni < N ? ni : N - 1;
+                xs_base = ((size_t)(ni / K) * T * K + (ni % K)) * HID + 4 * xs_c4;
+            }
+            float amax = 0.f;                    // range guard
+            auto chunk_load = [&](int chunk, float4 (&v)[2]) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    int t = chunk * TCH + xs_t + 4 * hf;
+                    t = t < T ? t : T - 1;
+                    v[hf] = *reinterpret_cast<const float4*>(zin + xs_base + (size_t)t * tstride);
+                }
+            };
+            auto chunk_store = [&](int chunk, const float4 (&v)[2]) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float f[4] = {v[hf].x, v[hf].y, v[hf].z, v[hf].w};
+                    h4v p0, p1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
+                        _Float16 a, b2;
+                        split_h2(f[e], a, b2);
+                        p0[e] = a; p1[e] = b2;
+                    }
+                    _Float16* dst = &xpl[((chunk & 1) * TCH + xs_t + 4 * hf) * TSTEP + ((xs_c4 >> 1) * 4 + xs_i) * 8 + (xs_c4 & 1) * 4];
+                    *reinterpret_cast<h4v*>(dst) = p0;
+                    *reinterpret_cast<h4v*>(dst + 4 * HID) = p1;
+                }
+            };
+            auto xslot = [&](int t) { return &xpl[(((t / TCH) & 1) * TCH + (t % TCH)) * TSTEP]; };
+            float4 xnext[2];
+            chunk_load(0, xnext); chunk_store(0, xnext);
+            if (TCH < T) chunk_load(1, xnext);
+            __syncthreads();
+            for (int g = 0; g < G; ++g) {
+                const int ch = g >> 1;
+                if (g && !(g & 1)) {                                  // first group of chunk ch >= 1
+                    lds_wait_ge(sync, SY_PIN0, 4 * (2 * ch - 2));    // the groups that read chunk ch - 2 (same slot) are published by every wave
+                    chunk_store(ch, xnext);
+                    lds_arrive(&sync[SY_X], lane);
+                    if ((ch + 1) * TCH < T) chunk_load(ch + 1, xnext);
+                    lds_wait_ge(sync, SY_X, 4 * ch);                 // every wave has stored its share of chunk ch
+                }
+                if (g >= 2) lds_wait_ge(sync, SY_DONE0, 16 * (g - 1));   // layer 0 has finished group g - 2 (same buffer)
+                stamp(0);
+                input_half(xslot(4 * g), g);
+                lds_arrive(&sync[SY_PIN0], lane);
+                stamp(2);
+            }
+            if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
+        } else {
+            // ---------------- H1: input half of layer 1 (A = h0 of the group, complete once layer 0 has finished its last step)
+            // FUSE: fc + residual of a group of layer 1 in two stages, so that H1 never waits for anything but its own gates: the
+            // residual rows of group f are REQUESTED in iteration f + 1 (fc_request) and the group is finished in iteration f + 2
+            // (fc_finish: A rows = (sequence, step) of h1 as in the batched input half, 6 MFMAs, epilogue), when the gate that
+            // iteration waits for anyway - layer 1 has finished group f - says its h1 is complete
+            float xres[4] = {0.f, 0.f, 0.f, 0.f};
+            auto fc_request = [&](int f) {
+                const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xres[e] = zin[base_q + (size_t)(ffirst + (e < nst ? e : nst - 1)) * tstride + unit];
+            };
+            auto fc_finish = [&](int f) {
+                const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
+                const _Float16* mine = &h1pl[((ffirst & (H1RING - 1)) + bstep) * TSTEP];
+                v4f fhi = zero4, flo = zero4;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const h8v f0 = *reinterpret_cast<const h8v*>(&mine[b * 128 + afrag]);
+                    const h8v f1 = *reinterpret_cast<const h8v*>(&mine[4 * HID + b * 128 + afrag]);
+                    const h8v wf0 = __builtin_bit_cast(h8v, wflds[(w4 * 4 + b * 2 + 0) * 64 + lane]);
+                    const h8v wf1 = __builtin_bit_cast(h8v, wflds[(w4 * 4 + b * 2 + 1) * 64 + lane]);
+                    fhi = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf0, fhi, 0, 0, 0);
+                    flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf1, flo, 0, 0, 0);
+                    flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, wf0, flo, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);                // one block's fragments at a time (registers)
+                }
+                lds_arrive(&sync[SY_FC], lane);                       // the group's h1 slots are free again
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nst && nq_raw < N) hout[base_q + (size_t)(ffirst + e) * tstride + unit] = ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + xres[e];
+            };
+            __syncthreads();
+            for (int g = 0; g < G; ++g) {
+                const int last = 4 * g + 4 < T ? 4 * g + 4 : T;
+                lds_wait_ge(sync, SY_DONE0, 4 * last);               // h0 of the group complete
+                if (g >= 2) lds_wait_ge(sync, SY_DONE1, 16 * (g - 1));   // layer 1 has finished group g - 2 (same buffer; its h1 is complete)
+                stamp(0);
+                input_half(&h0pl[((4 * g) & (H0RING - 1)) * TSTEP], g);
+                lds_arrive(&sync[SY_PIN1], lane);
+                stamp(2);
+                if (FUSE) {
+                    if (g >= 2) fc_finish(g - 2);
+                    if (g >= 1) fc_request(g - 1);
+                }
+                stamp(1);
+            }
+            if (FUSE) {                           // the last two groups
+                if (G >= 2) { lds_wait_ge(sync, SY_DONE1, 16 * (G - 1)); fc_finish(G - 2); }
+                fc_request(G - 1);
+                lds_wait_ge(sync, SY_DONE1, 4 * T);
+                fc_finish(G - 1);
+            }
+        }
+    }
+    if (lds_peek(&sync[SY_ABORT]) && range_flag) *range_flag = 3;
+    if (TRACE && lane == 0 && blockIdx.x < 4) {
+        unsigned long long* d = dbg + (blockIdx.x * 16 + wave) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = tp[k];
+    }
+}
+
+// The 16-wave kernel computes the block's fc + residual itself when the Linear layers are not asked to be exact fp32
+// (BSRNN_GEMM=f32 keeps every nn.Linear on the fp32 matrix kernels) - api.hip then skips the block's grouped-GEMM launch.
+// BSRNN_TIME_KERNEL = v2 (round-2 kernel, 8 waves) | v3 (16 waves, separate fc launch) | fused (default).
+static int time_kernel_variant()
+{
+    static const int v = [] {
+        const char* e = getenv("BSRNN_TIME_KERNEL");
+        if (!e || !*e || !strcmp(e, "fused")) return 2;
+        if (!strcmp(e, "v3")) return 1;
+        if (!strcmp(e, "v2")) return 0;
+        fprintf(stderr, "bsrnn: unknown BSRNN_TIME_KERNEL='%s' (v2 | v3 | fused), using fused\n", e);
+        return 2;
+    }();
+    return v;
+}
+bool time_lstm_fuses_fc()
+{
+    return lstm_mode() == LSTM_FP16X2 && !force_f32() && gemm_mode() != GEMM_F32 && time_kernel_variant() == 2;
+}
+
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream)
+                      const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,
+                      const void* fc16, const float* fcb)
 {
     const int N = R * K;
     if (N <= 0 || T <= 0) return;
-    dim3 grid((N + 3) / 4), block(512);
+    dim3 grid((N + 3) / 4), block(512), block16(1024);
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
-        hipLaunchKernelGGL(time_lstm_h2_kernel<false>, grid, block, 0, stream, zin, hout, (const uint4*)wpk16, bias, state_in, state_out, R, T, K,
-                           range_flag, (unsigned long long*)nullptr);
+        if (time_lstm_fuses_fc() && fc16 && fcb)
+            hipLaunchKernelGGL((time_lstm_h2w_kernel<true, false>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
+                               state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr);
+        else if (time_kernel_variant() >= 1)
+            hipLaunchKernelGGL((time_lstm_h2w_kernel<false, false>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)nullptr,
+                               (const float*)nullptr, state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL(time_lstm_h2_kernel<false>, grid, block, 0, stream, zin, hout, (const uint4*)wpk16, bias, state_in, state_out, R, T, K,
+                               range_flag, (unsigned long long*)nullptr);
         return;
     }
     hipLaunchKernelGGL(time_lstm_kernel, grid, block, 0, stream, zin, hout, wpk, bias, state_in, state_out, R, T, K,

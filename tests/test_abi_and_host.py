@@ -41,7 +41,7 @@ def test_header_symbols_are_exported(built):
     lib = ctypes.CDLL(built)
     for s in syms:
         assert hasattr(lib, s)
-    assert lib.bsrnn_abi_version() == 1
+    assert lib.bsrnn_abi_version() == 2
 
 
 def test_ladspa_plugin_exports_descriptor(built):

@@ -52,7 +52,7 @@ def model_hot(sd_hot):
 
 def test_native_library_is_loaded():
     from speechseparation_amd import _native
-    assert _native.lib.bsrnn_abi_version() == 1
+    assert _native.lib.bsrnn_abi_version() == 2
     assert "libbsrnn_hip.so" in open("/proc/self/maps").read()
 
 
