@@ -115,12 +115,14 @@ class BSRNN(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         self._plist = None
         self._epoch += 1
+        self._pushed_fingerprint = None     # (also tells a running StreamingSeparator to look at the weights at its next step)
         return out
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self._plist = None
         self._epoch += 1
+        self._pushed_fingerprint = None
         return out
 
     def set_range_policy(self, policy):
