@@ -975,6 +975,18 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             d.RT = RT; d.NW = 8 / GR; d.plane_units = units; d.nbias = nbias;
             d.in_off = ch == CHAIN_SPLIT ? c->poff[i] : i * H;
             d.K0 = ch == CHAIN_SPLIT ? round8(a) : H;
+            // a last feature tile with at most 4 real features (514 columns = 16 tiles + 2) is split over the k-steps of all eight
+            // waves instead of costing one wave a whole tile (mlp_chain.hip, split_host.h): the geometry that implements it is
+            // RT 2 / GR 1, and the partial sums need 8 KB of LDS behind the two activation images
+            static const bool rag_on = [] { const char* e = getenv("BSRNN_CHAIN_RAG"); return !(e && !strcmp(e, "0")); }();
+            if (rag_on && !g48 && RT == 2 && GR == 1 && 2 * img + CHAIN_RAG_LDS <= CHAIN_LDS_EX)
+                for (int l = 0; l < CHAIN_LAYERS; ++l) {
+                    const int tail = ld[l].N % 32;
+                    if (tail >= 1 && tail <= 4 && d.L[l].NTL >= 2) {
+                        d.L[l].rag = 1;
+                        cost -= (long)d.L[l].K16 - d.L[l].K16 / 8;
+                    }
+                }
             std::vector<uint16_t> stream;
             std::vector<float> biases(nbias, 0.f);
             for (int l = 0; l < CHAIN_LAYERS; ++l) {
@@ -983,7 +995,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
                 const Param& bi = P_(c, std::string(b) + ".bias");
                 d.L[l].w_off = (unsigned)(stream.size() * sizeof(uint16_t));
                 if (g48) pack_chain_layer16_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, 8, gmode == GEMM_FP16 ? 1 : 2, stream);
-                else pack_chain_layer_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, d.NW, gmode == GEMM_FP16 ? 1 : 2, stream);
+                else pack_chain_layer_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, d.NW, gmode == GEMM_FP16 ? 1 : 2, stream, d.L[l].rag);
                 memcpy(&biases[d.L[l].bias_off], bi.data.data(), ld[l].N * sizeof(float));
             }
             stream.resize((stream.size() + 7) & ~size_t(7), 0);

@@ -77,7 +77,9 @@ struct ChainLayer {
     int bias_off;        // first bias of the layer inside the chain's bias block (floats)
     int leaky;           // LeakyReLU(0.01) after the layer
     unsigned w_off;      // byte offset of the layer's fragment streams inside ChainDesc::wstream
+    int rag;             // 1: the last of the NTL feature tiles (<= 4 real features) is split over the k-steps of all waves (split_host.h)
 };
+constexpr int CHAIN_RAG_LDS = 8 * 1024;       // LDS behind the activation images that the partial sums of such a tile need
 struct ChainDesc {
     ChainLayer L[CHAIN_LAYERS];
     const void* wstream; // per layer, per wave wn: for tile t = wn + NW c, for ks, for piece: 64 lanes x 8 fp16 (split_host.h)

@@ -91,6 +91,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
     // GR = 8: every wave is a group of its own (one row tile, all feature tiles of the band, layers up to 128 wide): its
     // activation image is private, so the layer barriers are not needed (a wave's LDS accesses are performed in order)
     constexpr bool SOLO = GR == 8;
+    constexpr bool RAG = RT == 2 && GR == 1;      // the geometry that knows how to split a ragged last tile over the k-steps (host: ChainLayer::rag)
     auto group_barrier = [&]() { if (!SOLO) __syncthreads(); };
     float* const sbias = reinterpret_cast<float*>(smem_all + CHAIN_LDS_EX);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,20 +131,30 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
     // those of the waves before it.  (Wave-uniform base + 32-bit lane offset: saddr + voffset loads.)
     auto layer_stream = [&](int l, int& K16, int& cnt, gcc& wp) {
         K16 = dp->L[l].K16;
-        const int NTL = dp->L[l].NTL;
+        const int NTL = dp->L[l].NTL - dp->L[l].rag;            // whole tiles (a ragged last tile is split over the k-steps, below)
         const int full = NTL / NW, rem = NTL - full * NW;
         cnt = full + (wn < rem ? 1 : 0);
         int before = wn * full + (wn < rem ? wn : rem);
         if (CHAIN_ABL & 8) before = 0;             // measurement only: every wave streams wave 0's fragments (L1-hot for 7 of 8)
         wp = wbase + dp->L[l].w_off + (size_t)before * K16 * STEP;
     };
+    // the wave's k-slice [kr0, kr0 + kr) of the layer's ragged last tile and its fragment stream (behind all whole tiles)
+    auto rag_stream = [&](int l, int& kr0, int& kr, gcc& rp) {
+        const int K16 = dp->L[l].K16, base = K16 / NW, rem = K16 - base * NW;
+        kr0 = wn * base + (wn < rem ? wn : rem);
+        kr = base + (wn < rem ? 1 : 0);
+        rp = wbase + dp->L[l].w_off + ((size_t)(dp->L[l].NTL - 1) * K16 + kr0) * STEP;
+    };
     auto prefetch_layer = [&](int l) {
         int K16, cnt; gcc wp;
         layer_stream(l, K16, cnt, wp);
-        if (cnt > 0) {
+        // a layer with a ragged last tile starts with the wave's k-slice of it (set s: step s of the slice), then its whole tiles
+        int kr0 = 0, kr = 0; gcc rp = wbase;
+        if (RAG && dp->L[l].rag) rag_stream(l, kr0, kr, rp);
 #pragma unroll
-            for (int s = 0; s < PDR; ++s)
-                if (s < K16) wload(s, wp + (size_t)s * STEP);
+        for (int s = 0; s < PDR; ++s) {
+            if (s < kr) wload(s, rp + (size_t)s * STEP);
+            else if (cnt > 0 && s < K16) wload(s, wp + (size_t)s * STEP);
         }
     };
     prefetch_layer(0);
@@ -201,6 +212,9 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
         const int boff = dp->L[l].bias_off;
         const bool leaky = dp->L[l].leaky != 0;
         const bool to_p = CHAIN == CHAIN_SPLIT && l == 1;
+        const bool rag = RAG && dp->L[l].rag != 0;              // wave-uniform, the same for all waves of the workgroup
+        int kr0 = 0, kr = 0; gcc rp = wbase;
+        if (rag) rag_stream(l, kr0, kr, rp);
 
         // The K loop is bound by the CU's fill rate from L2 (~70 GB/s per CU, measured: tools/chain_bench.hip), so every
         // weight fragment a wave loads is multiplied with all RT row tiles of its group.  The wave works through its tiles one after the other: one accumulator pair per row tile, and PDR k-steps of
@@ -208,6 +222,47 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
         // layer's input from it), so it is kept split, as fp16 pieces, until the barrier.  Register set s holds k-step
         // ks0 + s; it is refilled right behind the MFMAs that consumed it, with the step PDR further on, or with the NEXT
         // tile's step s when this tile has no such step.
+        v4f* const rscr = reinterpret_cast<v4f*>(smem_all + CHAIN_LDS_EX - CHAIN_RAG_LDS);
+        // ---- the ragged last tile (<= 4 real features, e.g. columns 512, 513 of a 514-wide band: 17 tiles for 8 waves): every
+        // wave multiplies its k-slice of it (K16 / NW steps instead of one wave running a whole tile of K16) FIRST, while no finished
+        // tile occupies registers; the partial sums of the lanes that hold its first four features go to LDS and wave 0 adds them
+        // behind the layer's barrier.
+        if (rag) {
+            v16f hi[RT], lo[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) { hi[r] = (v16f){0}; lo[r] = (v16f){0}; }
+            for (int s0 = 0; s0 < kr; s0 += PDR) {
+#pragma unroll
+                for (int sx = 0; sx < PDR; ++sx) {
+                    if (s0 + sx < kr) {
+                        const int ks = kr0 + s0 + sx;
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) {
+                            h8 b[NPL];
+#pragma unroll
+                            for (int pc = 0; pc < NPL; ++pc) b[pc] = *reinterpret_cast<const h8*>(smem + r * img + pc * plane + ks * 1024 + lane * 16);
+                            if (NPL == 2) {
+                                lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[sx][0], b[NPL - 1], lo[r], 0, 0, 0);
+                                lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[sx][NPL - 1], b[0], lo[r], 0, 0, 0);
+                            }
+                            hi[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[sx][0], b[0], hi[r], 0, 0, 0);
+                        }
+                        if (s0 + sx + PDR < kr) wload(sx, rp + (size_t)(s0 + sx + PDR) * STEP);
+                        else if (cnt > 0 && sx < K16) wload(sx, wp + (size_t)sx * STEP);            // the first whole tile comes next
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    v4f pv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[e] = TERMS == 1 ? hi[r][e] : hi[r][e] + (1.f / 2048.f) * lo[r][e];
+                    rscr[(wn * RT + r) * 32 + m] = pv;
+                }
+            }
+        }
         h4 held[last ? 1 : CTR][RT][4][NPL];
 #pragma unroll
         for (int c = 0; c < CTR; ++c) {
@@ -341,14 +396,59 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                     }
                 }
         }
+        // wave 0 of the group: the ragged tile's features n0 .. n0 + 7 (lanes h = 0: the sum of the partials, h = 1: padding) through
+        // the same epilogue as a whole tile's first register quad; the padding up to the next layer's k range is written as zeros
+        auto rag_finish = [&]() {
+            const int t = dp->L[l].NTL - 1;
+            const int n0 = 32 * t + 4 * h;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
+                if (h == 0) {
+                    for (int w8 = 0; w8 < NW; ++w8) v += rscr[(w8 * RT + r) * 32 + m];
+                    const v4f bv = *reinterpret_cast<const v4f*>(&sbias[boff + n0]);
+                    v += bv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (leaky) v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                }
+                if (!last) {
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+                    h4 p0, p1;
+                    split4(v, p0, p1);
+                    const h4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    char* const d = smem + r * img + (4 * t) * 512 + m * 16 + 8 * h;
+                    *reinterpret_cast<h4*>(d) = p0;                       // k-unit 4 t: features n0 .. n0 + 7
+                    *reinterpret_cast<h4*>(d + 512) = z4;                 // k-unit 4 t + 1: padding
+                    if (NPL == 2) { *reinterpret_cast<h4*>(d + plane) = p1; *reinterpret_cast<h4*>(d + plane + 512) = z4; }
+                    if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0) = v;
+                } else if (CHAIN == CHAIN_SPLIT) {
+                    if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)row[r] * g.ldz + dp->z_off + n0) = v;
+                } else {
+                    if (row_ok[r] && n0 < dp->a8) {
+                        v += *(gc4)((gcf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0);
+                        if (g.tap) *(g4)((gf)g.tap + (size_t)row[r] * g.ldt + dp->p_off + n0) = v;
+                        *(g4)((gf)g.Y + (size_t)row[r] * g.ldy + dp->p_off + n0) = v * *(gc4)((gcf)g.Xmul + (size_t)row[r] * g.ldm + dp->p_off + n0);
+                    }
+                }
+            }
+        };
         // the next layer's first fragments: in flight across the barriers; where two row tiles' held pieces fill the
         // registers (RT = 2), only once those have gone to LDS
         constexpr bool XPRE = RT == 1;
         if (!last && XPRE) prefetch_layer(l + 1);
         stamp();
-        if (last) return;
+        if (last) {
+            if (rag) {
+                __syncthreads();
+                if (wn == 0) rag_finish();
+            }
+            return;
+        }
         group_barrier();                                         // every wave has read the layer's input image
         stamp();
+        if (rag && wn == 0) rag_finish();
 #pragma unroll
         for (int c = 0; c < CTR; ++c) {
             if (c >= cnt) break;

@@ -81,21 +81,37 @@ inline void pack_h2_slabs_host(const float* w, int N, int K, int ldw, int K32, i
 // (v_mfma_f32_32x32x16_f16: lane (r = l & 31, h = l >> 5) holds W[32 t + r][16 ks + 8 h + j], j < 8) and every wave of a
 // row tile walks its own linear stream: for wave wn of NW, for its tiles t = wn, wn + NW, ..., for k-step ks, for piece
 // (npl = 2: fp16x2, 1: plain fp16): 64 lanes x 8 halves = 1 KB.  Rows >= N and columns >= K are zeros.  Appends to `out`.
-inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out)
+// `rag` = 1: the last feature tile (which holds at most 4 real features: N % 32 in 1..4) is not given to one wave as a
+// whole tile but split over the k-steps: wave wn streams, BEHIND all the whole tiles of all waves, the fragments of its
+// k-slice [chain_rag_first(K16, NW, wn), chain_rag_first(K16, NW, wn + 1)) of that tile (the waves' partial sums are added
+// through LDS, mlp_chain.hip).  A band of 514 columns has 17 tiles for 8 waves: without this one wave runs 3 tiles where
+// the others run 2 and every layer takes 3 tile times instead of 2.1.
+inline int chain_rag_first(int K16, int NW, int wn)
 {
-    const int K16 = (K + 15) / 16, NTL = (N + 31) / 32;
+    const int base = K16 / NW, rem = K16 - base * NW;
+    return wn * base + (wn < rem ? wn : rem);
+}
+inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out, int rag = 0)
+{
+    const int K16 = (K + 15) / 16, NTL = (N + 31) / 32 - rag;
+    auto frag = [&](int t, int ks, int pc) {
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int n = 32 * t + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
+                const float v = (n < N && k < K) ? w[(size_t)n * ldw + k] : 0.f;
+                uint16_t p[2];
+                split_planes_host(&v, 1, 2, p);
+                out.push_back(p[pc]);
+            }
+    };
     for (int wn = 0; wn < NW; ++wn)
         for (int t = wn; t < NTL; t += NW)
             for (int ks = 0; ks < K16; ++ks)
-                for (int pc = 0; pc < npl; ++pc)
-                    for (int l = 0; l < 64; ++l)
-                        for (int j = 0; j < 8; ++j) {
-                            const int n = 32 * t + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
-                            const float v = (n < N && k < K) ? w[(size_t)n * ldw + k] : 0.f;
-                            uint16_t p[2];
-                            split_planes_host(&v, 1, 2, p);
-                            out.push_back(p[pc]);
-                        }
+                for (int pc = 0; pc < npl; ++pc) frag(t, ks, pc);
+    if (rag)
+        for (int wn = 0; wn < NW; ++wn)
+            for (int ks = chain_rag_first(K16, NW, wn); ks < chain_rag_first(K16, NW, wn + 1); ++ks)
+                for (int pc = 0; pc < npl; ++pc) frag(NTL, ks, pc);
 }
 
 // The same for the 48-row geometry on v_mfma_f32_16x16x32_f16 (feature tiles of 16, k-steps of 32): lane (n = l & 15,

@@ -76,6 +76,11 @@ int main(int argc, char** argv)
         }
         d.RT = RT; d.NW = 8 / GR; d.plane_units = units; d.nbias = nbias;
         d.in_off = chain ? i * H : poff[i]; d.K0 = chain ? H : d.a8;
+        if (!getenv("CHAIN_NORAG") && !g48 && RT == 2 && GR == 1 && 2 * img + CHAIN_RAG_LDS <= CHAIN_LDS_EX)
+            for (int l = 0; l < 5; ++l) {
+                const int N = chain ? dims_m[l][0] : dims_s[l][0];
+                if (N % 32 >= 1 && N % 32 <= 4 && d.L[l].NTL >= 2) d.L[l].rag = 1;
+            }
         bu.b.assign(nbias, 0.f);
         for (int l = 0; l < 5; ++l) {
             const int N = chain ? dims_m[l][0] : dims_s[l][0], Kd = chain ? dims_m[l][1] : dims_s[l][1];
@@ -83,7 +88,7 @@ int main(int argc, char** argv)
             for (auto& x : w) x = frand(seed) / sqrtf((float)Kd);
             d.L[l].w_off = (unsigned)(bu.w.size() * 2);
             if (g48) pack_chain_layer16_host(w.data(), N, Kd, Kd, 8, 2, bu.w);
-            else pack_chain_layer_host(w.data(), N, Kd, Kd, d.NW, 2, bu.w);
+            else pack_chain_layer_host(w.data(), N, Kd, Kd, d.NW, 2, bu.w, d.L[l].rag);
             for (int n = 0; n < N; ++n) bu.b[d.L[l].bias_off + n] = 0.1f * frand(seed);
         }
         wbytes_per_tile += g48 ? bu.w.size() * 2 * 32 / 48 : bu.w.size() * 2 / d.RT;      // per 32 rows: a wave group streams the weights once for its rows
