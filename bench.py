@@ -257,13 +257,20 @@ def plumbing_line(args, world, dist):
     nothing is measured): rendezvous over gloo, barrier, max-reduce, one JSON line from rank 0."""
     t = torch.tensor([1.0 + int(os.environ.get("RANK", "0"))], dtype=torch.float64)
     rccl_ranks = 1
+    per_rank = [float(t.item())]
     if dist is not None:
         dist.barrier()
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)                  # the same collectives, in the same order, as the measured path
+        per_rank = [float(a.item()) for a in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         rccl_ranks = dist.get_world_size()
+        if rccl_ranks != args.gpus:
+            sys.exit("bench.py: the process group has %d ranks, --gpus says %d" % (rccl_ranks, args.gpus))
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps({"metric": "separated row-frames/sec, batch64 8s@16kHz", "value": None, "unit": "row-frames/s", "n_gpus": world,
                           "rccl_ranks": rccl_ranks, "backend": "gloo", "steps": args.steps, "warmup": args.warmup, "max_over_ranks": float(t.item()),
+                          "per_rank": per_rank,
                           "data": "PLUMBING TEST: no kernels run, nothing measured"}), flush=True)
     if dist is not None:
         dist.barrier()

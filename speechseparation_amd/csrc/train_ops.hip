@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(TrainGemmGroup g)
         if (i >= total) break;
         const int m = (int)(i / jb.N), n = (int)(i % jb.N);
         const float gr = jb.A[(size_t)m * jb.lda + n];
-        jb.C[i] = jb.B[(size_t)m * jb.ldb + n] >= 0.f ? gr : 0.01f * gr;
+        jb.C[i] = jb.B[(size_t)m * jb.ldb + n] > 0.f ? gr : 0.01f * gr;       // (torch's leaky_relu_backward: slope 0.01 at exactly 0)
     }
 }
 

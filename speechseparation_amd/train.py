@@ -321,53 +321,107 @@ def sdr(x_time, s_time):
 
 # ------------------------------------------------------------------------------------------ optimizer and the step
 class AdamW:
-    """torch.optim.AdamW(params, lr=0.001, weight_decay=0.01) of train.py:50 on the library's kernel (one launch per tensor)."""
+    """torch.optim.AdamW(params, lr=0.001, weight_decay=0.01) of train.py:50 on the library's kernel (all tensors of a step in one
+    launch).  `state_dict()` / `load_state_dict()` speak torch.optim.AdamW's own format - {'state': {index: {'step', 'exp_avg',
+    'exp_avg_sq'}}, 'param_groups': [...]}, indices in `model.parameters()` order with the zero-size parameters counted - so the
+    reference's `optimizer.pth` / `optimizer-always.pth` (train.py:169-172) and the files written here interchange."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        self.params = [p for p in params if p.numel() > 0]
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.all_params = list(params)                      # model.parameters() order = the indices of torch's state_dict
+        self.slot = [i for i, p in enumerate(self.all_params) if p.numel() > 0]      # the ones the kernel updates
+        self.params = [self.all_params[i] for i in self.slot]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
-        self.t = 0
-        self._cache = None
+        self.steps = [0] * len(self.all_params)             # per parameter, like torch (a parameter without a gradient is not stepped)
+        self._cache = {}
+
+    @property
+    def t(self):
+        return max(self.steps) if self.steps else 0
 
     def zero_grad(self):
-        for p in self.params:
+        for p in self.all_params:
             p.grad = None
 
     @torch.no_grad()
     def step(self):
-        """All tensors that have a gradient in one launch (bsrnn_adamw_step_multi)."""
-        idx = [i for i, p in enumerate(self.params) if p.grad is not None]
-        if not idx:
-            return                                               # (torch counts a step only for parameters that have a gradient)
-        self.t += 1
-        grads = [_f32c(self.params[i].grad) for i in idx]
-        dev = self.params[idx[0]].device
-        n = len(idx)
-        key = tuple(idx)
-        if self._cache is None or self._cache[0] != key:        # the static arrays (parameters, moments, sizes) are built once
-            arr = lambda ts: (ctypes.c_void_p * n)(*[ts[i].data_ptr() for i in idx])      # noqa: E731
-            self._cache = (key, arr(self.params), arr(self.m), arr(self.v), (ctypes.c_int64 * n)(*[self.params[i].numel() for i in idx]))
-        _, ap, am, av, sizes = self._cache
-        ag = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
-        with torch.cuda.device(dev):
-            _native.check(_lib.bsrnn_adamw_step_multi(_context(dev), ap, ag, am, av, sizes, n, self.lr, self.betas[0], self.betas[1],
-                                                      self.eps, self.weight_decay, self.t, _s(dev)))
-        for i in idx:      # the kernel wrote the parameters behind torch's back: bump their version counters (BSRNN re-uploads
-            torch.autograd.graph.increment_version(self.params[i])      # its inference weights when a version changes)
+        """Every tensor that has a gradient, in one launch per distinct step count (bsrnn_adamw_step_multi; one launch normally)."""
+        for i, p in enumerate(self.all_params):
+            if p.grad is not None:
+                self.steps[i] += 1
+        idx_all = [j for j, p in enumerate(self.params) if p.grad is not None]
+        if not idx_all:
+            return
+        dev = self.params[idx_all[0]].device
+        for t in sorted({self.steps[self.slot[j]] for j in idx_all}):
+            idx = [j for j in idx_all if self.steps[self.slot[j]] == t]
+            grads = [_f32c(self.params[j].grad) for j in idx]
+            n = len(idx)
+            key = tuple(idx)
+            if key not in self._cache:                       # the static arrays (parameters, moments, sizes) are built once
+                arr = lambda ts: (ctypes.c_void_p * n)(*[ts[j].data_ptr() for j in idx])      # noqa: E731
+                self._cache = {key: (arr(self.params), arr(self.m), arr(self.v), (ctypes.c_int64 * n)(*[self.params[j].numel() for j in idx]))}
+            ap, am, av, sizes = self._cache[key]
+            ag = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+            with torch.cuda.device(dev):
+                _native.check(_lib.bsrnn_adamw_step_multi(_context(dev), ap, ag, am, av, sizes, n, self.lr, self.betas[0], self.betas[1],
+                                                          self.eps, self.weight_decay, t, _s(dev)))
+        for j in idx_all:  # the kernel wrote the parameters behind torch's back: bump their version counters (BSRNN re-uploads
+            torch.autograd.graph.increment_version(self.params[j])      # its inference weights when a version changes)
+
+    def _group_template(self):
+        """param_groups[0] with every key this torch version's AdamW carries (its load_state_dict adopts the saved group as is)."""
+        g = dict(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=self.lr, betas=self.betas, eps=self.eps,
+                                   weight_decay=self.weight_decay).state_dict()["param_groups"][0])
+        g["params"] = list(range(len(self.all_params)))
+        return g
 
     def state_dict(self):
-        """What `torch.save(optimizer.state_dict(), "optimizer.pth")` of train.py:169-172 keeps: step count and both moments."""
-        return {"step": self.t, "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
-                "exp_avg": [m.detach().cpu() for m in self.m], "exp_avg_sq": [v.detach().cpu() for v in self.v]}
+        """torch.optim.AdamW.state_dict() of the same optimizer: what train.py:169-172 saves."""
+        state = {}
+        pos = {i: j for j, i in enumerate(self.slot)}
+        for i, p in enumerate(self.all_params):
+            if self.steps[i] == 0:
+                continue                                     # torch creates a parameter's state at its first step
+            if i in pos:
+                m, v = self.m[pos[i]].detach().cpu().clone(), self.v[pos[i]].detach().cpu().clone()
+            else:
+                m, v = torch.zeros_like(p.detach().cpu()), torch.zeros_like(p.detach().cpu())
+            state[i] = {"step": torch.tensor(float(self.steps[i])), "exp_avg": m, "exp_avg_sq": v}
+        return {"state": state, "param_groups": [self._group_template()]}
 
     def load_state_dict(self, sd):
-        self.t = int(sd["step"])
-        for dst, src in zip(self.m, sd["exp_avg"]):
-            dst.copy_(src)
-        for dst, src in zip(self.v, sd["exp_avg_sq"]):
-            dst.copy_(src)
+        """Accepts torch.optim.AdamW.state_dict() (the reference's optimizer.pth) or what state_dict() above returns."""
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("expected a torch.optim.AdamW state_dict ({'state': ..., 'param_groups': [...]})")
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.all_params):
+            raise ValueError("optimizer state has %d parameter group(s) / %d parameters, the model has 1 / %d" % (
+                len(groups), len(groups[0]["params"]) if groups else 0, len(self.all_params)))
+        g = groups[0]
+        if g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("amsgrad / maximize optimizer states are not supported")
+        self.lr, self.betas, self.eps, self.weight_decay = float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        order = list(g["params"])                            # saved index of the parameter at each position
+        pos = {i: j for j, i in enumerate(self.slot)}
+        self.steps = [0] * len(self.all_params)
+        for m in self.m:
+            m.zero_()
+        for v in self.v:
+            v.zero_()
+        for i, saved in enumerate(order):
+            st = sd["state"].get(saved, sd["state"].get(str(saved)))
+            if st is None:
+                continue
+            self.steps[i] = int(round(float(st["step"])))
+            if i in pos:
+                if tuple(st["exp_avg"].shape) != tuple(self.params[pos[i]].shape):
+                    raise ValueError("optimizer state of parameter %d has shape %s, the model's is %s" % (
+                        i, tuple(st["exp_avg"].shape), tuple(self.params[pos[i]].shape)))
+                self.m[pos[i]].copy_(st["exp_avg"])
+                self.v[pos[i]].copy_(st["exp_avg_sq"])
+        self._cache = {}
 
 
 def train_step(model, optimizer, mix, speech, group=None, loss_sdr=False):

@@ -172,5 +172,48 @@ def main():
     load_ref(None)   # restore module
 
 
+def named_sizes():
+    """Round 3: fixtures at the sizes BASELINE.json / SURVEY 8(c) name.  Inputs regenerate from the seeded
+    generators (and, for spectra, from the same stock torch.stft call as infer.py:29-33), so only outputs are stored, plus a
+    thin subsample of each regenerated input to prove the regeneration."""
+    # ---- config 1: infer.py on one 4 s MONO 16 kHz mixture: 64 000 samples, duplicated to two rows (infer.py:26-27),
+    #      T = 63 frames, output 63 488 samples (infer.py:29-37)
+    _, m = load_ref(None, seed=0)
+    mono = torch.from_numpy(weights.synth_waveform(1, 64000, seed=41))
+    wave = torch.cat((mono, mono), 0)                                                       # infer.py:26-27
+    x = sandwich_in(wave)
+    y = m(x)
+    w_out = sandwich_out(y)
+    assert tuple(x.shape) == (2, 2050, 63) and tuple(w_out.shape) == (2, 63488)
+    # "Separation dB" of infer.py:44-47 on the same tensors (natural log, as the reference prints it)
+    sep = 10 * torch.log(torch.mean(torch.square(wave[:, :w_out.shape[1]])) / torch.mean(torch.square(wave[:, :w_out.shape[1]] - w_out)))
+    np.savez(os.path.join(HERE, "cfg1_sandwich.npz"), wave_out=w_out.numpy(), x_sub=x.numpy()[:, ::41, ::7].copy(),
+             y_sub=y.numpy()[:, ::41, ::7].copy(), separation_db=np.array([float(sep)], np.float64))
+    print("cfg1 sandwich", tuple(wave.shape), "->", tuple(w_out.shape), "separation dB", float(sep))
+
+    # ---- forward at R = 2 (two different rows), T = 63
+    wave2 = torch.from_numpy(weights.synth_waveform(2, 64000, seed=42))
+    x2 = sandwich_in(wave2)
+    t = taps_forward(m, x2)
+    y64 = m.double()(x2.double()).numpy()
+    m.float()
+    np.savez(os.path.join(HERE, "fwd_T63.npz"), y=t["y"], x_sub=x2.numpy()[:, ::41, ::7].copy(), mask_sub=t["mask"][:, ::41, ::7].copy(),
+             z_after_3_sub=t["z_after_3"][:, ::7].copy(), y64_sub=y64[:, ::41, ::7].copy())
+    print("fwd_T63 |y|max", np.abs(t["y"]).max(), "fp32-fp64", np.abs(t["y"] - y64).max())
+
+    # ---- 41-band table, hot weights (LSTM matrices x 3), R = 2, T = 8, with the dual-path taps
+    v41 = spec.variant_bandsplits("41")
+    _, m41 = load_ref(v41, seed=4, lstm_gain=3.0)
+    x41 = sandwich_in(torch.from_numpy(weights.synth_waveform(2, 7 * 1024, seed=9)))
+    t41 = taps_forward(m41, x41)
+    np.savez(os.path.join(HERE, "bands41_hot_T8.npz"), v=np.array(v41, np.int64), x_sub=x41.numpy()[:, ::41, :].copy(), **t41)
+    print("bands41 hot", tuple(x41.shape), "|y|max", np.abs(t41["y"]).max())
+    load_ref(None)   # restore module
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "named":
+        named_sizes()
+    else:
+        main()
+        named_sizes()

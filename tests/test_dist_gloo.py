@@ -81,6 +81,7 @@ def test_bench_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3
     assert d["max_over_ranks"] == 2.0                    # rank 1's value won the MAX reduce
+    assert d["per_rank"] == [1.0, 2.0]                   # every rank's own figure reaches rank 0 (all_gather)
 
 
 def test_bench_refuses_a_world_that_contradicts_gpus():

@@ -1,0 +1,199 @@
+"""Fixtures at the sizes BASELINE.json / SURVEY 8(c) name, produced by the reference itself
+(tests/golden/make_golden.py `named`): config 1 (infer.py on one 4 s mono 16 kHz mixture: 64 000 -> 63 488 samples, T = 63),
+`forward` at R = 2, T = 63, and the 41-band table with hot weights at R = 2, T = 8 with the dual-path taps.  Inputs regenerate from the
+seeded generators through the same stock torch.stft call as infer.py:29-33 (a thin subsample of every regenerated input is stored
+to prove it).  CPU: the oracle against them; -m gpu: the HIP path against them, plus config 3's longest chunk (L = 256) against
+offline and config 2 at full size against the oracle on a corner."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_ORACLE = 3e-5            # fp32 restatement vs the reference (its own fp32-vs-fp64 distance here: 5e-6)
+TOL = 1e-4                   # north star, HIP path vs the reference
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def sandwich_in(wave):
+    """infer.py:29-33 with the reference's own calls (as tests/golden/make_golden.py)."""
+    w = torch.from_numpy(np.ascontiguousarray(wave))
+    X = torch.stft(w, n_fft=2048, hop_length=1024, return_complex=True, window=torch.hann_window(2048))
+    x = torch.stack((X.real, X.imag), dim=2)
+    return x.reshape((x.shape[0], x.shape[1] * 2, x.shape[3])).numpy()
+
+
+def inputs(name):
+    from speechseparation_amd import weights
+    if name == "cfg1":
+        mono = weights.synth_waveform(1, 64000, seed=41)
+        wave = np.concatenate((mono, mono), 0)                       # infer.py:26-27
+    elif name == "fwd_T63":
+        wave = weights.synth_waveform(2, 64000, seed=42)
+    else:
+        wave = weights.synth_waveform(2, 7 * 1024, seed=9)
+    return wave, sandwich_in(wave)
+
+
+def test_inputs_regenerate():
+    for name, fix, sub in (("cfg1", "cfg1_sandwich", (slice(None), slice(None, None, 41), slice(None, None, 7))),
+                           ("fwd_T63", "fwd_T63", (slice(None), slice(None, None, 41), slice(None, None, 7))),
+                           ("b41", "bands41_hot_T8", (slice(None), slice(None, None, 41), slice(None)))):
+        _, x = inputs(name)
+        assert maxabs(x[sub], golden(fix)["x_sub"]) < 2e-6, name      # torch.stft on another host: rounding-level differences at most
+
+
+def test_oracle_at_the_named_sizes(sd_default):
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    g = golden("fwd_T63")
+    _, x = inputs("fwd_T63")
+    taps = {}
+    y = onp.forward(sd_default, x, taps=taps)
+    assert y.shape == (2, 2050, 63) and maxabs(y, g["y"]) < TOL_ORACLE
+    assert maxabs(taps["mask"][:, ::41, ::7], g["mask_sub"]) < TOL_ORACLE and maxabs(taps["z_after_3"][:, ::7], g["z_after_3_sub"]) < TOL_ORACLE
+    y64 = onp.forward(sd_default, x.astype(np.float64), dtype=np.float64)
+    assert maxabs(y64[:, ::41, ::7], g["y64_sub"]) < 2e-6              # (x itself is a float32 regeneration)
+    g = golden("cfg1_sandwich")
+    wave, _ = inputs("cfg1")
+    out = onp.separate(sd_default, wave)
+    assert out.shape == (2, 63488) and maxabs(out, g["wave_out"]) < TOL_ORACLE
+    ref, db, _ = onp.infer_outputs(sd_default, wave)
+    assert abs(db - float(g["separation_db"][0])) < 1e-3
+    g = golden("bands41_hot_T8")
+    v = g["v"].tolist()
+    sd41 = weights.synth_state_dict(v, seed=4, lstm_gain=3.0)
+    _, x41 = inputs("b41")
+    taps = {}
+    y = onp.forward(sd41, x41, v, taps=taps)
+    assert maxabs(y, g["y"]) < TOL_ORACLE and maxabs(taps["mask"], g["mask"]) < TOL_ORACLE
+    for j in range(4):
+        assert maxabs(taps["z_after_%d" % j], g["z_after_%d" % j]) < TOL_ORACLE, j
+
+
+def make_model(sd, v=None):
+    from speechseparation_amd.bsrnn import BSRNN
+    m = BSRNN(v).eval()
+    m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd.items()}, strict=True)
+    return m.to("cuda")
+
+
+@pytest.mark.gpu
+def test_hip_config1_sandwich_and_forward_T63(sd_default):
+    m = make_model(sd_default)
+    g = golden("cfg1_sandwich")
+    wave, x = inputs("cfg1")
+    out = m.separate(torch.from_numpy(wave).cuda()).cpu().numpy()
+    e = maxabs(out, g["wave_out"])
+    print("config 1 sandwich 64000 -> %d samples: max |hip - reference| %.3e" % (out.shape[1], e))
+    assert out.shape == (2, 63488) and e < TOL
+    assert np.array_equal(out[0], out[1])                           # the duplicated mono rows stay identical
+    assert maxabs(m(torch.from_numpy(x).cuda()).cpu().numpy()[:, ::41, ::7], g["y_sub"]) < TOL
+    g = golden("fwd_T63")
+    _, x = inputs("fwd_T63")
+    y, mask = m.forward_with_mask(torch.from_numpy(x).cuda())
+    e = maxabs(y.cpu().numpy(), g["y"])
+    print("forward R = 2, T = 63: max |hip - reference| %.3e (|y|max %.3g)" % (e, np.abs(g["y"]).max()))
+    assert e < TOL and maxabs(mask.cpu().numpy()[:, ::41, ::7], g["mask_sub"]) < TOL
+    # the same frames one by one through forward_recurrent (state carried): the reference's structural invariant at T = 63
+    state = torch.zeros((4, 2, 24, 64), device="cuda")
+    xt = torch.from_numpy(x).cuda()
+    ys = []
+    for t in range(63):
+        yt, state = m.forward_recurrent(xt[:, :, t].contiguous(), state)
+        ys.append(yt)
+    assert maxabs(torch.stack(ys, 2).cpu().numpy(), g["y"]) < TOL
+
+
+@pytest.mark.gpu
+def test_hip_41_bands_hot_with_taps():
+    from speechseparation_amd import weights
+    g = golden("bands41_hot_T8")
+    v = g["v"].tolist()
+    m = make_model(weights.synth_state_dict(v, seed=4, lstm_gain=3.0), v)
+    _, x = inputs("b41")
+    y, mask = m.forward_with_mask(torch.from_numpy(x).cuda())
+    e_y, e_m = maxabs(y.cpu().numpy(), g["y"]), maxabs(mask.cpu().numpy(), g["mask"])
+    z, _ = m.dual_path(torch.from_numpy(g["z0"]).cuda())
+    e_z = maxabs(z.cpu().numpy(), g["z_after_3"])
+    print("41 bands, hot weights, R = 2, T = 8: y %.3e  mask %.3e  dual path (saturated gates) %.3e" % (e_y, e_m, e_z))
+    assert e_y < TOL and e_m < TOL and e_z < 5e-5
+
+
+@pytest.mark.gpu
+def test_hip_infer_cli_on_the_4_second_file(tmp_path, sd_default):
+    """config 1 as named: infer.py --input <4 s mono 16 kHz> : the written file against the reference's own output."""
+    from speechseparation_amd import audio
+    g = golden("cfg1_sandwich")
+    wave, _ = inputs("cfg1")
+    src, dst = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    audio.save_wav(src, torch.from_numpy(wave[:1].copy()), 16000)   # float WAV: the samples survive exactly
+    r = subprocess.run([sys.executable, os.path.join(REPO, "infer.py"), "--input", src, "--output", dst, "--synthetic-weights", "0",
+                        "--outdir", str(tmp_path)], capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got, sr = audio.load_wav(dst)
+    assert sr == 16000 and tuple(got.shape) == (2, 63488)
+    assert maxabs(got.numpy(), g["wave_out"]) < TOL
+    printed = float(r.stdout.split("Separation dB")[1].split()[0])
+    assert abs(printed - float(g["separation_db"][0])) < 1e-2
+
+
+@pytest.mark.gpu
+def test_hip_chunks_of_256_frames_equal_offline(sd_default):
+    """config 3's longest chunk: L = 256 frames per call with state carry (two rows, and the metric's 64 rows), against the
+    offline forward of the same frames and, for a corner, against the oracle."""
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    m = make_model(sd_default)
+    for R, tol in ((2, 3e-5), (64, 3e-5)):
+        wave = weights.synth_waveform(R, 511 * 1024 + 9, seed=60 + R)        # T = 512 = two chunks of 256
+        x = m.stft(torch.from_numpy(wave).cuda())
+        assert x.shape[2] == 512
+        y_off = m(x)
+        state = torch.zeros((4, 2, R * 12, 64), device="cuda")
+        ys = []
+        for a in (0, 256):
+            y, state = m.forward_chunk(x[:, :, a:a + 256].contiguous(), state)
+            ys.append(y)
+        e = maxabs(torch.cat(ys, 2).cpu().numpy(), y_off.cpu().numpy())
+        print("R = %d: two chunks of 256 frames vs offline %.3e" % (R, e))
+        assert e < tol
+        if R == 2:
+            ref = onp.forward(sd_default, x[:, :, :6].cpu().numpy())
+            assert maxabs(y_off[:, :, :6].cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.gpu
+def test_hip_config2_full_size_against_the_oracle_corner(sd_default):
+    """config 2 as named (R = 32 x 8 s, 16-bit GEMM operands: BSRNN_GEMM=fp16, the one-term fp16 mode standing in for the bf16 the
+    config names) at full size, in a child process (the mode is read once per process): the first frames of two rows against the
+    fp32 oracle run on just those frames (the model is causal in time) - within the mode's stated 1e-2 of the output range."""
+    code = r'''
+import sys, numpy as np, torch
+from oracle import bsrnn_numpy as onp
+from speechseparation_amd import weights, _native
+from speechseparation_amd.bsrnn import BSRNN
+sd = weights.synth_state_dict(None, seed=0)
+m = BSRNN().eval(); m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd.items()}); m = m.to("cuda")
+assert _native.compute_mode()["gemm"] == "fp16"
+w = weights.synth_waveform(32, 128000, seed=1234)
+x = m.stft(torch.from_numpy(w).cuda())
+y = m(x)
+ref = onp.forward(sd, x[:2, :, :8].cpu().numpy())
+rel = float(np.abs(y[:2, :, :8].cpu().numpy() - ref).max() / np.abs(ref).max())
+print("REL", rel, bool(torch.isfinite(y).all()), tuple(y.shape))
+'''
+    env = dict(os.environ, PYTHONPATH=REPO, BSRNN_GEMM="fp16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rel, finite, shape = r.stdout.split("REL")[1].split(None, 2)
+    print("config 2 (fp16 operands) full size vs fp32 oracle on rows 0-1, frames 0-7: %s of the range" % rel)
+    assert float(rel) < 1e-2 and finite == "True" and "(32, 2050, 126)" in shape

@@ -7,8 +7,9 @@ Reference flow per epoch: for every training clip `train_infer` (STFT -> BSRNN -
 weight_decay 1e-2; :50), then a validation pass without gradients and the checkpoints `model.pth` (best validation loss) /
 `model-always.pth` (+ `optimizer*.pth`).  Same flags: --datapath --mini --batch_size --resume --loss_sdr.
 
-Data: <datapath>/{tr,val}/<clip>/{mixture,speech}.wav (the DnR layout of m_dataset.samples(), :8-19, as 16-bit / float WAV: the
-reference's .flac needs torchaudio, absent here), or --synthetic N clips of seeded noise (no dataset ships with the reference).
+Data: <datapath>/{train,val}/<clip>/{mixture,speech}.wav - the folders the reference trains from (`samples(args.datapath, 'train')` /
+`'val'`, train.py:58,74; DnR layout of m_dataset.samples(), :8-19), as 16-bit / float WAV (the reference's .flac needs torchaudio, absent
+here); a `tr/` folder (DnR v2's name) is used when there is no `train/`; --train-folder / --val-folder override, or --synthetic N clips of seeded noise (no dataset ships with the reference).
 Not carried over: wandb logging, the discriminator, the RIR / re-mix augmentations, ReduceLROnPlateau (commented out in the
 reference loop) and its batch-size growth heuristic.  Under `torchrun` (one process per GPU) the clips are split over the ranks
 and the gradients averaged before every optimizer step (data-parallel, RCCL).
@@ -60,6 +61,8 @@ def main(argv=None):
     ap.add_argument("--mini", action="store_true", help="Use a small dataset")
     ap.add_argument("--batch_size", type=int, default=1, help="Batch size")
     ap.add_argument("--resume", action="store_true", help="Reload model")
+    ap.add_argument("--train-folder", type=str, default=None, help="training split under --datapath (default: train, else tr)")
+    ap.add_argument("--val-folder", type=str, default="val", help="validation split under --datapath")
     ap.add_argument("--loss_sdr", action="store_true", help="Use SDR as loss")
     ap.add_argument("--epochs", type=int, default=1, help="epochs to run (the reference loops until interrupted)")
     ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="N synthetic training clips (and N // 4 + 1 for validation)")
@@ -80,14 +83,17 @@ def main(argv=None):
     if args.synthetic:
         train_set, val_set = list(range(args.synthetic)), list(range(args.synthetic, args.synthetic + args.synthetic // 4 + 1))
     elif args.datapath:
-        train_set, val_set = dataset(args.datapath, "tr"), dataset(args.datapath, "val")
+        # the reference's live path reads `train` and `val` (train.py:58,74); DnR's own split is called `tr`
+        tf = args.train_folder or ("train" if os.path.isdir(os.path.join(args.datapath, "train")) else "tr")
+        train_set, val_set = dataset(args.datapath, tf), dataset(args.datapath, args.val_folder)
     else:
         ap.error("give --datapath DIR or --synthetic N")
     if args.mini:
         random.Random(0).shuffle(train_set)
         train_set, val_set = train_set[:10], val_set[:10]
     if not train_set:
-        raise SystemExit("no training clips found under %s/tr/*/{mixture,speech}.wav" % args.datapath)
+        raise SystemExit("no training clips found under %s/{train,tr}/*/{mixture,speech}.wav (WAV copies of the reference's .flac; "
+                         "--train-folder names another split)" % args.datapath)
 
     model = BSRNN().train()
     if args.synthetic_weights is not None:
