@@ -192,6 +192,11 @@ __global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __
                                                    int64_t n, int T, int sch)
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
+#ifdef FFT_EXCLUSIVE_LDS
+    // measurement only (tools/coresident_variants.sh): the workgroup claims the CU's whole LDS, so no other kernel's waves share its CU
+    __shared__ float lds_pad[(160 * 1024 - 2 * 1024 * 8) / 4 - 64];
+    { volatile float* vp = lds_pad; float t_ = vp[threadIdx.x]; asm volatile("" :: "v"(t_)); }
+#endif
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<false>(tb.tw1024, tid);
     const SplitCtx spl = load_split(tb, tid, false);
@@ -290,6 +295,11 @@ void launch_istft_backward(const FftTables& tb, const float* dwave, float* scrat
 __global__ __launch_bounds__(256) void istft_fused_kernel(FftTables tb, const float* __restrict__ Y, float* __restrict__ out, int T, int ich)
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
+#ifdef FFT_EXCLUSIVE_LDS
+    // measurement only (tools/coresident_variants.sh): the workgroup claims the CU's whole LDS, so no other kernel's waves share its CU
+    __shared__ float lds_pad[(160 * 1024 - 2 * 1024 * 8) / 4 - 64];
+    { volatile float* vp = lds_pad; float t_ = vp[threadIdx.x]; asm volatile("" :: "v"(t_)); }
+#endif
     const int tid = threadIdx.x;
     const Twiddles twd = load_twiddles<true>(tb.tw1024, tid);
     const SplitCtx spl = load_split(tb, tid, true);

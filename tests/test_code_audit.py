@@ -1,7 +1,12 @@
-"""CPU: audit of the shipped gfx950 code object.  The co-residency hazard of round 1 came with the SLP
-vectorizer's packed-fp32 code: v_pk_* instructions with op_sel / neg operand modifiers and v_pk_mov_b32 in the FFT kernels.
-The library is built without that vectorizer; this test keeps it that way by disassembling the device code inside
-libbsrnn_hip.so: packed fp32 may only appear in the plain forms the hand-written vector code produces."""
+"""CPU: audit of the shipped gfx950 code object.  The co-residency hazard (notebook section "co-residency hazard";
+profiles/r03_vpk_hazard.txt): STFT / iSTFT kernels whose butterflies the SLP vectorizer had turned into packed-fp32 code
+(v_pk_add / mul / fma_f32, v_pk_mov_b32) returned whole frames of garbage WHILE WAVES OF ANOTHER KERNEL SHARED THEIR CU (beside
+GEMM / LSTM launches: 4-20 of 20 runs wrong), never alone, and never when their workgroups were made to own the CU (all of its LDS
+claimed: 0 of 80 runs wrong with the same vectorised code).  Forced-zero wait counts do not change it, LDS guard bands do not,
+scalar fp32 code does not show it.  The victims were kernels that issue no MFMA of their own; the kernels that do (GEMM, chains,
+LSTMs) run hand-written packed fp32 beside MFMA waves all the time and stay bit-stable beside other kernels (tests/test_gpu_coresident.py).
+The library is therefore built without the SLP vectorizer, and this test holds the rule the evidence supports on the code that
+ships: a kernel that issues no MFMA contains no packed-fp32 instruction at all."""
 import os
 import re
 import struct
@@ -34,19 +39,29 @@ def device_code_objects(path):
 
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
-def test_no_modified_packed_fp32_in_the_shipped_kernels(tmp_path):
+def test_packed_fp32_only_in_kernels_that_issue_mfma(tmp_path):
     if not os.path.exists(LIB):
         import __graft_entry__
         __graft_entry__.build()
     objs = [(t, b) for t, b in device_code_objects(LIB) if "gfx950" in t and len(b) > 0]
     assert objs, "no gfx950 code object found in %s" % LIB
-    total = 0
+    n_kernels = n_pk = 0
     for i, (triple, data) in enumerate(objs):
         f = tmp_path / ("dev%d.co" % i)
         f.write_bytes(data)
         asm = subprocess.run([OBJDUMP, "-d", str(f)], capture_output=True, text=True, check=True).stdout
-        pk = [ln for ln in asm.splitlines() if re.search(r"\bv_pk_(add|mul|fma|mov)_(f32|b32)\b", ln)]
-        total += len(pk)
-        bad = [ln.strip() for ln in pk if "v_pk_mov_b32" in ln or re.search(r"op_sel:|neg_lo:|neg_hi:", ln)]
-        assert not bad, "packed fp32 with operand modifiers in %s: %s" % (triple, bad[:5])
-    assert total > 0      # the disassembly worked: the GEMM split and the LSTM cells do use plain v_pk_mul / add / fma
+        cur, stats = None, {}
+        for ln in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+            if m:
+                cur = m.group(1)
+                stats[cur] = [0, 0]
+            elif cur is not None:
+                stats[cur][0] += "v_mfma" in ln
+                stats[cur][1] += bool(re.search(r"\bv_pk_(add|mul|fma)_f32\b|\bv_pk_mov_b32\b", ln))
+        bad = sorted(k for k, (mfma, pk) in stats.items() if pk and not mfma)
+        assert not bad, "packed fp32 in kernels without MFMA (%s): %s" % (triple, bad[:5])
+        n_kernels += len(stats)
+        n_pk += sum(1 for v in stats.values() if v[1])
+    # the disassembly worked: the DSP kernels are there, and the GEMM split / LSTM cells do use packed fp32
+    assert n_kernels > 20 and n_pk > 0
