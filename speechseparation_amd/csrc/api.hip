@@ -99,6 +99,8 @@ struct bsrnn_ctx {
     const void *bandW16[2][2], *timeW16[2];
     const void* timeFc16[2] = {nullptr, nullptr};   // the time blocks' fc as fp16x2 B fragments (fused into the time-axis launch, lstm.hip)
     const float* timeFcB[2] = {nullptr, nullptr};
+    const void* bandFc16[2] = {nullptr, nullptr};   // the band blocks' fc (128 -> 64) likewise, for the few-sequence kernel (band_block_small_kernel)
+    const float* bandFcB[2] = {nullptr, nullptr};
     int *h_range = nullptr, *d_range = nullptr;    // range guard of the fp16x2 kernels: host-mapped word the kernels set                     // fp16x2 pieces in MFMA operand order (lstm.hip)
     float* d_tables = nullptr;
     float* d_train_ws = nullptr;       // grow-only scratch of the training entry points (stream-ordered reuse: one call at a time)
@@ -139,19 +141,22 @@ constexpr int MAX_PARTS = 4;
 struct bsrnn_stream {
     bsrnn_ctx* ctx;
     int C;
-    float *buf, *prev, *state, *X, *Y, *chunk, *out;
-    float* mixp;                       // device word holding the wet/dry control (read by the synthesis kernel)
-    int mix_bits = 0; bool mix_set = false; hipStream_t mix_stream = nullptr;      // what it was last set to (a 4-byte fill is a launch)
+    // What a step carries to the next one - the sliding analysis buffer, the previous synthesis frame and the LSTM state - exists
+    // twice: step k reads set k & 1 and writes the other one, so a step whose operands leave the fp16 range can be run again,
+    // exactly, from its untouched starting point (range policy, finish_call), without a copy per step.
+    float *base = nullptr;             // the one allocation
+    float *buf[2], *prev[2], *state[2];
+    int cur = 0;                       // the set the NEXT step reads
+    float *X, *Y, *chunk, *out;
     float *h_in = nullptr, *h_out = nullptr;   // pinned staging for the host-buffer entry point
-    // One step = ~27 tiny launches; its buffers are fixed, so the whole step is captured once into a
-    // hipGraph and replayed (launch-bound inner loop: 477 us eager per step at C = 2).
-    hipGraphExec_t exec = nullptr;
-    hipGraph_t graph = nullptr;
+    // One step = analysis, ~18 launches of the model, synthesis.  The model part works on fixed buffers (X -> Y, state set p -> set
+    // 1 - p), so it is captured once per parity into a hipGraph and replayed (launch-bound inner loop); the two DSP kernels are
+    // launched around it with the caller's own chunk / output pointers and the wet/dry control as a kernel argument (no staging copies).
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    hipGraph_t graph[2] = {nullptr, nullptr};
     hipStream_t cap = nullptr;
     bool use_graph = true;
-    unsigned gen = 0;                  // context generation the graph was captured against
-    float* shadow = nullptr;           // copy of {buf, prev, state} taken before a synchronous step (range-guard re-run)
-    size_t carry_floats = 0;           // size of that region
+    unsigned gen = 0;                  // context generation the graphs were captured against
 };
 
 namespace {
@@ -457,12 +462,18 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     case MS_BAND0: case MS_BAND1: {   // BandwiseLSTM: N = M sequences of length K   bsrnn.py:138-153
         const int blk = stage == MS_BAND1;
         StageScope sc(c, ST_BAND_LSTM, s);
+        if (band_block_is_small(M, K)) {          // a few frame rows (streaming): the whole block, fc + residual included, in one launch
+            launch_band_block_small(p.Z0, p.Z1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1],
+                                    c->bandFc16[blk], c->bandFcB[blk], M, K, c->d_range, s);
+            break;
+        }
         launch_band_lstm(p.Z0, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
         launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);
         break;
     }
     case MS_BANDFC0: case MS_BANDFC1: {
         const int blk = stage == MS_BANDFC1;
+        if (band_block_is_small(M, K)) break;     // done inside the band launch
         StageScope sc(c, ST_BAND_FC, s);
         gemm_slot(c, BLK_FC0 + 2 * blk, p.HB1, 2 * HID, p.Z1, HID, p.Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
         break;
@@ -1019,7 +1030,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
     }
 
     // LSTM weights, folded and packed in the kernels' register order (lstm.hip)
-    size_t o_bandW[2][2], o_bandW16[2][2], o_bandB[2][2], o_timeW[2], o_timeW16[2], o_timeB[2], o_timeFc16[2], o_timeFcB[2];
+    size_t o_bandW[2][2], o_bandW16[2][2], o_bandB[2][2], o_timeW[2], o_timeW16[2], o_timeB[2], o_timeFc16[2], o_timeFcB[2], o_bandFc16[2], o_bandFcB[2];
     std::vector<double> wcat, bsum;
     for (int blk = 0; blk < 2; ++blk) {
         const int jb_ = 2 * blk;                               // lstms.0 / lstms.2: bidirectional over bands
@@ -1057,6 +1068,25 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             o_bandW[blk][layer] = ar.put(pk);
             o_bandB[blk][layer] = ar.put(pb);
             o_bandW16[blk][layer] = ar.put(reinterpret_cast<const float*>(pk16.data()), pk16.size() / 2);
+        }
+        {   // the block's fc (128 -> 64, bsrnn.py:84) as fp16x2 B fragments for band_block_small_kernel: [4 tile][4 blk][2 piece][64 lane][8],
+            // lane (n = l & 15, kb = l >> 4) holds W_fc[16 tile + n][32 blk + 8 kb .. + 7]
+            snprintf(b, sizeof b, "lstms.%d.m.fc.weight", jb_); const Param& wfc = P_(c, b);
+            snprintf(b, sizeof b, "lstms.%d.m.fc.bias", jb_); const Param& bfc = P_(c, b);
+            std::vector<uint16_t> f16((size_t)4 * 4 * 2 * 64 * 8);
+            for (int tl = 0; tl < 4; ++tl)
+                for (int bk = 0; bk < 4; ++bk)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = wfc.data[(size_t)(16 * tl + (ln & 15)) * 2 * H + 32 * bk + 8 * (ln >> 4) + e];
+                            uint16_t pc[2];
+                            split_planes_host(&v, 1, 2, pc);
+                            const size_t base = ((size_t)tl * 4 + bk) * 2;
+                            f16[((base + 0) * 64 + ln) * 8 + e] = pc[0];
+                            f16[((base + 1) * 64 + ln) * 8 + e] = pc[1];
+                        }
+            o_bandFc16[blk] = ar.put(reinterpret_cast<const float*>(f16.data()), f16.size() / 2);
+            o_bandFcB[blk] = ar.put(bfc.data);
         }
         const int jt = 2 * blk + 1;                            // lstms.1 / lstms.3: causal over time
         std::vector<float> pk((size_t)2 * 4 * 128 * 64), pb(2 * 256);
@@ -1149,6 +1179,8 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         c->timeW[blk] = c->d_arena + o_timeW[blk];
         c->timeW16[blk] = c->d_arena + o_timeW16[blk];
         c->timeB[blk] = c->d_arena + o_timeB[blk];
+        c->bandFc16[blk] = c->d_arena + o_bandFc16[blk];
+        c->bandFcB[blk] = c->d_arena + o_bandFcB[blk];
         c->timeFc16[blk] = c->d_arena + o_timeFc16[blk];
         c->timeFcB[blk] = c->d_arena + o_timeFcB[blk];
     }
@@ -1290,9 +1322,14 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
     HIP_TRY(hipMemcpyAsync(c->Z0, z, nz * sizeof(float), hipMemcpyDeviceToDevice, s));
     const size_t slab = (size_t)2 * 2 * C * K * HID;
     for (int blk = 0; blk < 2; ++blk) {
-        launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
-        launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);
-        gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+        if (band_block_is_small(M, K)) {
+            launch_band_block_small(c->Z0, c->Z1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1],
+                                    c->bandFc16[blk], c->bandFcB[blk], M, K, c->d_range, s);
+        } else {
+            launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
+            launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);
+            gemm_slot(c, BLK_FC0 + 2 * blk, c->HB1, 2 * HID, c->Z1, HID, c->Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
+        }
         const bool fused = time_lstm_fuses_fc();
         launch_time_lstm(c->Z1, fused ? c->Z0 : c->H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
                          state_out ? state_out + blk * slab : nullptr, C, T, K, c->d_range, s, c->timeFc16[blk], c->timeFcB[blk]);
@@ -1709,8 +1746,7 @@ int bsrnn_evaluate(bsrnn_ctx* c, const float* mix, const float* speech, int32_t 
 
 
 // --------------------------------------------------------------------------- streaming
-// Device layout of a stream object: [buf | prev | state] (everything a step carries to the next one, contiguous so that
-// one copy snapshots it), its shadow, then the per-step scratch [X | Y | chunk | out | mix].
+// Device layout of a stream object: two carry sets [buf | prev | state] (see bsrnn_stream), then the per-step scratch [X | Y | chunk | out].
 static size_t stream_carry_floats(const bsrnn_ctx* c, int C) { return (size_t)C * NFFT * 2 + (size_t)4 * 2 * C * c->K * HID; }
 static size_t stream_total_floats(const bsrnn_ctx* c, int C)
 {
@@ -1728,32 +1764,40 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     st->ctx = c; st->C = C;
     const size_t nstate = (size_t)4 * 2 * C * c->K * HID;
     const size_t total = stream_total_floats(c, C);
-    st->carry_floats = stream_carry_floats(c, C);
     float* p = nullptr;
     hipError_t e = hipMalloc((void**)&p, total * sizeof(float));
     if (e != hipSuccess) { delete st; return fail(BSRNN_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
-    st->buf = p; p += (size_t)C * NFFT;
-    st->prev = p; p += (size_t)C * NFFT;
-    st->state = p; p += nstate;
-    st->shadow = p; p += st->carry_floats;
+    st->base = p;
+    for (int k = 0; k < 2; ++k) {
+        st->buf[k] = p; p += (size_t)C * NFFT;
+        st->prev[k] = p; p += (size_t)C * NFFT;
+        st->state[k] = p; p += nstate;
+    }
     st->X = p; p += (size_t)C * c->LDP;
     st->Y = p; p += (size_t)C * c->LDP;
     st->chunk = p; p += (size_t)C * HOPS;
     st->out = p; p += (size_t)C * HOPS;
-    st->mixp = p;
     st->use_graph = getenv("BSRNN_NO_GRAPH") == nullptr;
     if (hipHostMalloc((void**)&st->h_in, (size_t)C * HOPS * sizeof(float), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&st->h_out, (size_t)C * HOPS * sizeof(float), hipHostMallocDefault) != hipSuccess) {
-        (void)hipFree(st->buf); delete st; return fail(BSRNN_EHIP, "hipHostMalloc failed");
+        (void)hipFree(st->base); delete st; return fail(BSRNN_EHIP, "hipHostMalloc failed");
     }
-    e = hipMemset(st->buf, 0, total * sizeof(float));
-    if (e != hipSuccess) { (void)hipFree(st->buf); delete st; return fail(BSRNN_EHIP, "hipMemset: %s", hipGetErrorString(e)); }
+    e = hipMemset(st->base, 0, total * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(st->base); delete st; return fail(BSRNN_EHIP, "hipMemset: %s", hipGetErrorString(e)); }
     rc = ensure_ws(c, C);
     if (!rc) rc = ensure_tasks(c, C);
-    if (rc) { (void)hipFree(st->buf); delete st; return rc; }
+    if (rc) { (void)hipFree(st->base); delete st; return rc; }
     ++c->live_streams;
     *out = st;
     return 0;
+}
+
+static void stream_drop_graph(bsrnn_stream* st)
+{
+    for (int k = 0; k < 2; ++k) {
+        if (st->exec[k]) { (void)hipGraphExecDestroy(st->exec[k]); st->exec[k] = nullptr; }
+        if (st->graph[k]) { (void)hipGraphDestroy(st->graph[k]); st->graph[k] = nullptr; }
+    }
 }
 
 void bsrnn_stream_destroy(bsrnn_stream* st)
@@ -1762,12 +1806,11 @@ void bsrnn_stream_destroy(bsrnn_stream* st)
     bsrnn_ctx* c = st->ctx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    if (st->exec) (void)hipGraphExecDestroy(st->exec);
-    if (st->graph) (void)hipGraphDestroy(st->graph);
+    stream_drop_graph(st);
     if (st->cap) (void)hipStreamDestroy(st->cap);
     if (st->h_in) (void)hipHostFree(st->h_in);
     if (st->h_out) (void)hipHostFree(st->h_out);
-    (void)hipFree(st->buf);
+    (void)hipFree(st->base);
     delete st;
     if (--c->live_streams == 0 && c->zombie) destroy_now(c);     // bsrnn_destroy() came first: the context goes with its last stream
 }
@@ -1776,61 +1819,43 @@ int bsrnn_stream_reset(bsrnn_stream* st, void* stream)
 {
     if (!st) return fail(BSRNN_EARG, "null stream");
     HIP_TRY(hipSetDevice(st->ctx->device));
-    HIP_TRY(hipMemsetAsync(st->buf, 0, stream_total_floats(st->ctx, st->C) * sizeof(float), (hipStream_t)stream));
-    st->mix_set = false;                   // (the control word lives in the same allocation)
+    HIP_TRY(hipMemsetAsync(st->base, 0, stream_total_floats(st->ctx, st->C) * sizeof(float), (hipStream_t)stream));
+    st->cur = 0;
     return 0;
 }
 
-// the launches of one streaming step on the stream object's own buffers (st->chunk -> st->out)
-static int stream_step_launches(bsrnn_stream* st, hipStream_t s)
+// One step from carry set p = st->cur into set 1 - p: chunk -> out (device pointers of the caller or the object's own buffers).
+// The model part is a graph replay when possible.  Does NOT flip st->cur: the caller does, once the step is known to be good.
+static int stream_step_run(bsrnn_stream* st, const float* chunk, float* out, float mix, hipStream_t s)
 {
     bsrnn_ctx* c = st->ctx;
-    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_analysis(c->tb, st->buf, st->chunk, st->X, st->C, s); }
-    int rc = run_model(c, st->X, st->Y, nullptr, st->C, 1, st->state, st->state, s);
-    if (rc) return rc;
-    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_synthesis(c->tb, st->Y, st->X, st->mixp, st->prev, st->out, st->C, s); }
-    return 0;
-}
-
-static void stream_drop_graph(bsrnn_stream* st)
-{
-    if (st->exec) { (void)hipGraphExecDestroy(st->exec); st->exec = nullptr; }
-    if (st->graph) { (void)hipGraphDestroy(st->graph); st->graph = nullptr; }
-}
-
-// one step on the stream object's own buffers (st->chunk -> st->out), by graph replay when possible
-static int stream_step_run(bsrnn_stream* st, float mix, hipStream_t s)
-{
-    bsrnn_ctx* c = st->ctx;
+    const int p = st->cur, q = p ^ 1;
     int rc;
-    int mix_bits;
-    memcpy(&mix_bits, &mix, sizeof mix_bits);
-    if (!st->mix_set || st->mix_bits != mix_bits || st->mix_stream != s) {      // the control rarely changes: no fill launch per chunk
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)st->mixp, mix_bits, 1, s));
-        st->mix_bits = mix_bits; st->mix_set = true; st->mix_stream = s;
-    }
+    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_analysis(c->tb, st->buf[p], st->buf[q], chunk, st->X, st->C, s); }
     if (st->use_graph && c->prof == 0 && !force_f32()) {
-        // The captured step holds the context's workspace and weight-arena pointers.  A larger call on the context (workspace
+        // The captured launches hold the context's workspace and weight-arena pointers.  A larger call on the context (workspace
         // regrown) or a re-commit of the parameters (arena rebuilt) since the capture changes ctx->gen: capture again
         // instead of replaying launches that point into freed memory.
-        if (st->exec && st->gen != c->gen) {
+        if ((st->exec[0] || st->exec[1]) && st->gen != c->gen) {
             HIP_TRY(hipDeviceSynchronize());
             stream_drop_graph(st);
         }
-        if (!st->exec) {
+        if (!st->exec[p]) {
             if (!st->cap) HIP_TRY(hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking));
             HIP_TRY(hipStreamBeginCapture(st->cap, hipStreamCaptureModeThreadLocal));
-            rc = stream_step_launches(st, st->cap);
-            hipError_t e = hipStreamEndCapture(st->cap, &st->graph);
+            rc = run_model(c, st->X, st->Y, nullptr, st->C, 1, st->state[p], st->state[q], st->cap);
+            hipError_t e = hipStreamEndCapture(st->cap, &st->graph[p]);
             if (rc) return rc;
             if (e != hipSuccess) return fail(BSRNN_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            HIP_TRY(hipGraphInstantiate(&st->exec, st->graph, nullptr, nullptr, 0));
+            HIP_TRY(hipGraphInstantiate(&st->exec[p], st->graph[p], nullptr, nullptr, 0));
             st->gen = c->gen;
         }
-        HIP_TRY(hipGraphLaunch(st->exec, s));
-    } else if ((rc = stream_step_launches(st, s))) {
+        HIP_TRY(hipGraphLaunch(st->exec[p], s));
+    } else if ((rc = run_model(c, st->X, st->Y, nullptr, st->C, 1, st->state[p], st->state[q], s))) {
         return rc;
     }
+    { StageScope sc(c, ST_STREAM_DSP, s); launch_stream_synthesis(c->tb, st->Y, st->X, mix, st->prev[p], st->prev[q], out, st->C, s); }
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1843,21 +1868,17 @@ int bsrnn_stream_step(bsrnn_stream* st, const float* chunk, float* out, float mi
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
     if ((rc = ensure_ws(c, st->C)) || (rc = ensure_tasks(c, st->C))) return rc;
-    const size_t nb = (size_t)st->C * HOPS * sizeof(float);
-    if (chunk != st->chunk) HIP_TRY(hipMemcpyAsync(st->chunk, chunk, nb, hipMemcpyDeviceToDevice, s));
-    // default range policy in a split-precision mode: keep what the step is about to overwrite (analysis buffer, previous
-    // synthesis frame, LSTM state), so that a step whose operands leave the fp16 range can be run again, exactly, from the
-    // same starting point (finish_call)
-    const bool guarded = c->range_policy == BSRNN_RANGE_EXACT && c->h_range && !force_f32() && (gemm_mode() != GEMM_F32 || lstm_mode() != LSTM_F32);
-    if (guarded) HIP_TRY(hipMemcpyAsync(st->shadow, st->buf, st->carry_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if ((rc = stream_step_run(st, mix, s))) return rc;
-    if ((rc = finish_call(c, s, [&]() -> int {
-            HIP_TRY(hipMemcpyAsync(st->buf, st->shadow, st->carry_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
-            return stream_step_run(st, mix, s);
-        })))
-        return rc;
-    if (out != st->out) HIP_TRY(hipMemcpyAsync(out, st->out, nb, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipGetLastError());
+    const float* src = chunk;
+    if (chunk == out && c->range_policy == BSRNN_RANGE_EXACT) {
+        // in place: a re-run (range policy) must still see the input, so it is kept aside first
+        HIP_TRY(hipMemcpyAsync(st->chunk, chunk, (size_t)st->C * HOPS * sizeof(float), hipMemcpyDeviceToDevice, s));
+        src = st->chunk;
+    }
+    if ((rc = stream_step_run(st, src, out, mix, s))) return rc;
+    // default range policy: wait, look at the guard, and if an operand left the fp16 range run the step again on the exact-fp32
+    // kernels from the same (untouched) carry set
+    if ((rc = finish_call(c, s, [&]() -> int { return stream_step_run(st, src, out, mix, s); }))) return rc;
+    st->cur ^= 1;
     return 0;
 }
 
@@ -1889,8 +1910,8 @@ int bsrnn_stream_get_state(bsrnn_stream* st, float* state_host)
     HIP_TRY(hipSetDevice(st->ctx->device));
     HIP_TRY(hipDeviceSynchronize());
     const size_t nstate = (size_t)4 * 2 * st->C * st->ctx->K * HID;
-    HIP_TRY(hipMemcpy(state_host, st->state, nstate * sizeof(float), hipMemcpyDeviceToHost));
-    return check_range(st->ctx);          // asynchronous steps report a range violation here (or at the next call / bsrnn_sync)
+    HIP_TRY(hipMemcpy(state_host, st->state[st->cur], nstate * sizeof(float), hipMemcpyDeviceToHost));
+    return check_range(st->ctx);          // steps made under the 'deferred' policy report a range violation here (or at the next call / bsrnn_sync)
 }
 
 // --------------------------------------------------------------------------- measurement

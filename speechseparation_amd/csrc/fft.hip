@@ -403,8 +403,8 @@ void launch_from_frame_major(const FftTables& tb, const float* yf, float* y, int
 }
 
 // ------------------------------------------------------------------------------ streaming DSP
-__global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, float* __restrict__ buf, const float* __restrict__ chunk,
-                                                              float* __restrict__ X)
+__global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, const float* __restrict__ buf_in, float* __restrict__ buf,
+                                                              const float* __restrict__ chunk, float* __restrict__ X)
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     const int tid = threadIdx.x;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, floa
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int cc = tid + 256 * i;                 // complex index 0..511 of each half
-        keep[i] = *reinterpret_cast<const float2*>(b + HOPS + 2 * cc);
+        keep[i] = *reinterpret_cast<const float2*>(buf_in + (size_t)c * NFFT + HOPS + 2 * cc);
         fresh[i] = *reinterpret_cast<const float2*>(ch + 2 * cc);
     }
     __syncthreads();
@@ -436,9 +436,9 @@ __global__ __launch_bounds__(256) void stream_analysis_kernel(FftTables tb, floa
 }
 
 __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, const float* __restrict__ Y, const float* __restrict__ X,
-                                                               const float* __restrict__ mix_dev, float* __restrict__ prev, float* __restrict__ out)
+                                                               const float mix, const float* __restrict__ prev_in, float* __restrict__ prev,
+                                                               float* __restrict__ out)
 {
-    const float mix = *mix_dev;      // device word: the step is replayed from a hipGraph, the control value changes per call
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
     __shared__ __attribute__((aligned(16))) float spec[F2 + 2];
     const int tid = threadIdx.x;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, con
     for (int i = 0; i < 2; ++i) {
         const int cc = tid + 256 * i;                 // samples 2cc, 2cc+1 of the first half
         const float2 now = make_float2(z[cc].x * sc, z[cc].y * sc);
-        const float2 old = *reinterpret_cast<const float2*>(pv + HOPS + 2 * cc);
+        const float2 old = *reinterpret_cast<const float2*>(prev_in + (size_t)c * NFFT + HOPS + 2 * cc);
         *reinterpret_cast<float2*>(o + 2 * cc) =
             make_float2((now.x + old.x) * tb.inv_wsum[2 * cc], (now.y + old.y) * tb.inv_wsum[2 * cc + 1]);
     }
@@ -474,13 +474,14 @@ __global__ __launch_bounds__(256) void stream_synthesis_kernel(FftTables tb, con
         *reinterpret_cast<float2*>(pv + 2 * cc) = make_float2(z[cc].x * sc, z[cc].y * sc);
 }
 
-void launch_stream_analysis(const FftTables& tb, float* buf, const float* chunk, float* X, int C, hipStream_t s)
+void launch_stream_analysis(const FftTables& tb, const float* buf_in, float* buf_out, const float* chunk, float* X, int C, hipStream_t s)
 {
-    hipLaunchKernelGGL(stream_analysis_kernel, dim3(C), dim3(256), 0, s, tb, buf, chunk, X);
+    hipLaunchKernelGGL(stream_analysis_kernel, dim3(C), dim3(256), 0, s, tb, buf_in, buf_out, chunk, X);
 }
-void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, const float* mix_dev, float* prev, float* out, int C, hipStream_t s)
+void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, float mix, const float* prev_in, float* prev_out, float* out,
+                             int C, hipStream_t s)
 {
-    hipLaunchKernelGGL(stream_synthesis_kernel, dim3(C), dim3(256), 0, s, tb, Y, X, mix_dev, prev, out);
+    hipLaunchKernelGGL(stream_synthesis_kernel, dim3(C), dim3(256), 0, s, tb, Y, X, mix, prev_in, prev_out, out);
 }
 
 }  // namespace bsrnn

@@ -126,6 +126,12 @@ void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 //         [2 dir][4 wave][(IN+64)/32 blk][4 gate][2 piece][64 lane][8]
 void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       int N, int L, int IN, int* range_flag, hipStream_t stream);
+// The whole band-axis block (both layers, both directions, fc + residual) of a few sequences in one workgroup: the streaming
+// step's N = C frame rows.  w0pk16 / w1pk16 / bias0 / bias1 are launch_band_lstm's arguments of the two layers; fc16 the block's
+// fc (128 -> 64) as fp16x2 B fragments [4 tile][4 blk][2 piece][64 lane][8], fcb its bias.  zout = fc(h1) + b + zin.
+bool band_block_is_small(int N, int L);
+void launch_band_block_small(const float* zin, float* zout, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
+                             const void* fc16, const float* fcb, int N, int L, int* range_flag, hipStream_t stream);
 // How the recurrent layers evaluate their gate products (environment BSRNN_LSTM = f32 | fp16x2, read once).
 enum LstmMode { LSTM_F32 = 0, LSTM_FP16X2 = 2 };
 int lstm_mode();
@@ -233,12 +239,13 @@ void launch_istft_backward(const FftTables& tb, const float* dwave, float* scrat
 // [C][2050][T] (reference layout) <-> [C*T][ld] (band-padded)
 void launch_to_frame_major(const FftTables& tb, const float* x, float* xf, int C, int T, hipStream_t s);
 void launch_from_frame_major(const FftTables& tb, const float* yf, float* y, int C, int T, hipStream_t s);
-// streaming DSP, one frame per row (infer-streaming.py:116-145)
-//   analysis: buf [C][2048] slides by 1024, appends chunk [C][1024]; X [C][ld] = rfft(buf*hann)
-//   synthesis: s = irfft(mix(Y, X)); out = (s[0:1024] + prev[1024:2048]) * inv_wsum; prev = s
-void launch_stream_analysis(const FftTables& tb, float* buf, const float* chunk, float* X, int C, hipStream_t s);
-void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, const float* mix_dev,
-                             float* prev, float* out, int C, hipStream_t s);
+// streaming DSP, one frame per row (infer-streaming.py:116-145).  What a step carries to the next one is read from one buffer and
+// written to another (the stream object alternates two sets): a step can be run again from its unchanged starting point.
+//   analysis: buf_out [C][2048] = [buf_in[:, 1024:], chunk [C][1024]]; X [C][ld] = rfft(buf_out * hann)
+//   synthesis: s = irfft(mix(Y, X)); out = (s[0:1024] + prev_in[1024:2048]) * inv_wsum; prev_out = s
+void launch_stream_analysis(const FftTables& tb, const float* buf_in, float* buf_out, const float* chunk, float* X, int C, hipStream_t s);
+void launch_stream_synthesis(const FftTables& tb, const float* Y, const float* X, float mix, const float* prev_in, float* prev_out, float* out,
+                             int C, hipStream_t s);
 
 // ------------------------------------------------------------------ validation metrics (metrics.hip)
 // Per-workgroup partial sums in double; the host adds them.  est [R][n_est]; speech, mix [R][n_in] (first n_est used).

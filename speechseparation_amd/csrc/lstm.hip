@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #ifndef BAND_NLDS
 #define BAND_NLDS 2                 // second-piece weight blocks of the 128-input layer kept in LDS (3: 226 VGPRs, 2: 242, 1: 254)
@@ -1220,6 +1221,178 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 4; ++k) d[k] = tp[k];
     }
+}
+
+// =====================================================================================
+// Band-axis block for a HANDFUL of sequences (the one-frame streaming step: N = C frame rows = 2 sequences of K = 12 bands):
+// BandwiseLSTM's whole NormRNNResidual (bsrnn.py:138-153, :78-87) - layer 0 in both directions, layer 1 in both directions,
+// fc(128 -> 64) + bias + residual - in ONE workgroup per four sequences, instead of two band_lstm_h2 launches (two 4-wave
+// workgroups each on an otherwise empty chip, 15 + 18 us of which the 16 x 16 tile with 2 of 16 columns used is the least
+// problem: every step pays 48 / 72 MFMAs per wave) and a grouped-GEMM launch.  Same fp16x2 arithmetic.
+// Organisation = the time-axis kernel's: activations are the A operand with row 4j = sequence j's first piece and row 4j + 1
+// its second piece (one MFMA against w1 gives a1 w1 and a2 w1, one against w2 gives a1 w2: two MFMAs per (gate, k block)
+// instead of three), weights the B operand (tile g = gate g of the wave's 16 units) - the packed weights of band_lstm_h2 are
+// exactly those fragments (api.hip) - so lane (n, q) owns the cell (unit 16 w + n, sequence q).  Waves 0-3 run the forward
+// direction, waves 4-7 the backward one; one barrier per step; all L positions of x, of layer 0's output and of layer 1's
+// output stay in LDS as fp16 pieces ([k / 8][sequence][8] per position), the fc at the end batches four positions per tile.
+// =====================================================================================
+constexpr int BS_MAXL = 16;                     // positions (bands) the LDS images hold; longer band tables take the general kernels
+constexpr int BS_XSTEP = TSTEP;                 // halves per position of the 64-wide x image (2 pieces x [8][4][8] + skew)
+constexpr int BS_HSTEP = 2 * 4 * 2 * HID + 32;  // halves per position of a 128-wide image (forward | backward halves)
+
+__global__ __launch_bounds__(512) void band_block_small_kernel(const float* __restrict__ zin, float* __restrict__ zout,
+                                                               const uint4* __restrict__ w0pk, const float* __restrict__ bias0,
+                                                               const uint4* __restrict__ w1pk, const float* __restrict__ bias1,
+                                                               const uint4* __restrict__ wfc, const float* __restrict__ bfc,
+                                                               int N, int L, int* __restrict__ range_flag)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[BS_MAXL * BS_XSTEP];          // x_t, 64 wide
+    __shared__ __attribute__((aligned(16))) _Float16 h0pl[(BS_MAXL + 1) * BS_HSTEP];   // layer 0 output, slot L = zeros (h_{-1})
+    __shared__ __attribute__((aligned(16))) _Float16 h1pl[(BS_MAXL + 1) * BS_HSTEP];   // layer 1 output, slot L = zeros
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = wave >> 2, w4 = wave & 3;
+    const int n = lane & 15, q = lane >> 4;
+    const int unit = 16 * w4 + n;
+    const int n0 = blockIdx.x * 4;
+    const int nq_raw = n0 + q;
+    const int nq = nq_raw < N ? nq_raw : N - 1;
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- x -> fp16 pieces in LDS (4 sequences x L positions x 16 float4), zero slots for h_{-1}
+    float amax = 0.f;
+    for (int i = tid; i < 4 * L * 16; i += 512) {
+        const int c4 = i & 15, sq = (i >> 4) & 3, t = i >> 6;
+        const int ns = n0 + sq < N ? n0 + sq : N - 1;
+        const float4 v = *reinterpret_cast<const float4*>(zin + ((size_t)ns * L + t) * HID + 4 * c4);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        h4v p0, p1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
+            _Float16 a, b2;
+            split_h2(f[e], a, b2);
+            p0[e] = a; p1[e] = b2;
+        }
+        _Float16* dst = &xpl[t * BS_XSTEP + ((c4 >> 1) * 4 + sq) * 8 + (c4 & 1) * 4];
+        *reinterpret_cast<h4v*>(dst) = p0;
+        *reinterpret_cast<h4v*>(dst + 4 * HID) = p1;
+    }
+    for (int i = tid; i < BS_HSTEP / 8; i += 512) {
+        *reinterpret_cast<uint4*>(&h0pl[L * BS_HSTEP + 8 * i]) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(&h1pl[L * BS_HSTEP + 8 * i]) = make_uint4(0, 0, 0, 0);
+    }
+
+    // A fragment of a 32-deep k block inside one piece of an image: row l & 15 carries sequence (l & 15) >> 2, and rows 4j + 1
+    // read the SECOND piece (which lies `pstride` halves behind the first)
+    const int afrag = (q * 4 + (n >> 2)) * 8;
+    const bool second = (n & 3) == 1;
+    const int hoff = ((unit >> 3) * 4 + q) * 8 + (unit & 7);      // this lane's h inside the 64 k of its direction
+
+    // one LSTM layer of this wave's direction: x image `ximg` (NBX k blocks of 32 per position, pieces XP halves apart),
+    // output image `himg` (this direction's 64 k start at k-unit 8 dir; pieces 4 * 2 * HID halves apart)
+    auto layer = [&](auto nbx_tag, const _Float16* ximg, const int xstep, const int XP, _Float16* himg, const uint4* wpk, const float* bias) {
+        constexpr int NBX = decltype(nbx_tag)::value, NB = NBX + 2;
+        h8v w[NB][4][2];
+        {
+            const uint4* wp = wpk + ((size_t)(dir * 4 + w4) * NB * 4 * 2) * 64 + lane;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[((b * 4 + gte) * 2 + pc) * 64]);
+        }
+        float bs[4];
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[dir * 256 + gte * 64 + unit];
+        float c = 0.f;
+        const int HP = 4 * 2 * HID;                              // halves between the two pieces of a 128-wide image
+        for (int step = 0; step < L; ++step) {
+            const int t = dir ? L - 1 - step : step;
+            const int tprev = step == 0 ? L : (dir ? t + 1 : t - 1);      // slot L holds zeros
+            h8v a[NB];
+            const _Float16* xs = ximg + t * xstep + (second ? XP : 0) + afrag;
+#pragma unroll
+            for (int b = 0; b < NBX; ++b) a[b] = *reinterpret_cast<const h8v*>(xs + b * 128);
+            const _Float16* hs = himg + tprev * BS_HSTEP + (second ? HP : 0) + dir * 256 + afrag;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) a[NBX + b] = *reinterpret_cast<const h8v*>(hs + b * 128);
+            v4f hi[4], lo[4];
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) { hi[gte] = zero4; lo[gte] = zero4; }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[b], w[b][gte][0], hi[gte], 0, 0, 0);
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[b], w[b][gte][1], lo[gte], 0, 0, 0);
+            }
+            // hi[g] = {a1 w1, a2 w1, -, -}, lo[g] = {a1 w2, -, -, -} of this lane's cell (unit, sequence q)
+            const float ig = fast_sigmoid(bs[0] + (hi[0][0] + (hi[0][1] + lo[0][0]) * (1.f / 2048.f)));
+            const float fg = fast_sigmoid(bs[1] + (hi[1][0] + (hi[1][1] + lo[1][0]) * (1.f / 2048.f)));
+            const float gg = fast_tanh(bs[2] + (hi[2][0] + (hi[2][1] + lo[2][0]) * (1.f / 2048.f)));
+            const float og = fast_sigmoid(bs[3] + (hi[3][0] + (hi[3][1] + lo[3][0]) * (1.f / 2048.f)));
+            c = fg * c + ig * gg;
+            const float hv = og * fast_tanh(c);
+            _Float16 p0, p1;
+            split_h2(hv, p0, p1);
+            _Float16* hb = himg + t * BS_HSTEP + dir * 256 + hoff;
+            hb[0] = p0;
+            hb[HP] = p1;
+            __syncthreads();
+        }
+    };
+    __syncthreads();
+    layer(std::integral_constant<int, 2>(), xpl, BS_XSTEP, 4 * HID, h0pl, w0pk, bias0);          // layer 0: x is 64 wide
+    layer(std::integral_constant<int, 4>(), h0pl, BS_HSTEP, 4 * 2 * HID, h1pl, w1pk, bias1);     // layer 1: x = layer 0, both directions
+
+    // ---- fc(128 -> 64) + bias + residual, four positions per 16-row tile: row 4j + r = (sequence j, position 4 g + r); wave =
+    // (group of positions, 16 output features) pairs
+    const int groups = (L + 3) >> 2;
+    const int bstep = n & 3;
+    for (int task = wave; task < 4 * groups; task += 8) {
+        const int tile = task & 3, g4 = task >> 2;
+        int tpos = 4 * g4 + bstep;
+        tpos = tpos < L ? tpos : L - 1;
+        const _Float16* mine = h1pl + tpos * BS_HSTEP + afrag;
+        v4f fhi = zero4, flo = zero4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const h8v f0 = *reinterpret_cast<const h8v*>(mine + b * 128);
+            const h8v f1 = *reinterpret_cast<const h8v*>(mine + 4 * 2 * HID + b * 128);
+            const h8v wf0 = __builtin_bit_cast(h8v, wfc[((tile * 4 + b) * 2 + 0) * 64 + lane]);
+            const h8v wf1 = __builtin_bit_cast(h8v, wfc[((tile * 4 + b) * 2 + 1) * 64 + lane]);
+            fhi = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf0, fhi, 0, 0, 0);
+            flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf1, flo, 0, 0, 0);
+            flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, wf0, flo, 0, 0, 0);
+        }
+        const int feat = 16 * tile + n;
+        const float bf = bfc[feat];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 4 * g4 + r;
+            if (t < L && nq_raw < N) {
+                const size_t o = ((size_t)nq * L + t) * HID + feat;
+                zout[o] = ((fhi[r] + flo[r] * (1.f / 2048.f)) + bf) + zin[o];
+            }
+        }
+    }
+    if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
+}
+
+// true when launch_band_block_small() will take the block (fp16x2 modes, few sequences, a band table that fits the LDS images)
+bool band_block_is_small(int N, int L)
+{
+    static const bool on = [] { const char* e = getenv("BSRNN_BAND_SMALL"); return !(e && !strcmp(e, "0")); }();
+    return on && lstm_mode() == LSTM_FP16X2 && !force_f32() && gemm_mode() != GEMM_F32 && N >= 1 && N <= 8 && L >= 1 && L <= BS_MAXL;
+}
+void launch_band_block_small(const float* zin, float* zout, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
+                             const void* fc16, const float* fcb, int N, int L, int* range_flag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(band_block_small_kernel, dim3((N + 3) / 4), dim3(512), 0, stream, zin, zout, (const uint4*)w0pk16, bias0,
+                       (const uint4*)w1pk16, bias1, (const uint4*)fc16, fcb, N, L, range_flag);
 }
 
 // The 16-wave kernel computes the block's fc + residual itself when the Linear layers are not asked to be exact fp32
