@@ -132,7 +132,9 @@ int  bsrnn_io_info(const bsrnn_ctx* ctx, int32_t index, int32_t C, const char** 
  *     x_dev [C, 2050, T] -> y_dev [C, 2050, T]   (y = x * mask; x is not modified)
  * bsrnn_forward_recurrent  = BSRNN.forward_recurrent  (bsrnn.py:445-510)
  *     x_dev [C, 2050], state_in_dev [4, 2, C*K, 64] -> y_dev [C, 2050], state_out_dev (same
- *     shape; may alias state_in_dev).  State slabs: 0/1 = h/c of lstms.1, 2/3 = h/c of
+ *     shape; a DIFFERENT buffer under BSRNN_RANGE_EXACT - BSRNN_EARG otherwise: a call that left the
+ *     fp16 range is run again from state_in_dev -, may alias it under BSRNN_RANGE_DEFERRED; the same
+ *     holds for bsrnn_forward_chunk and bsrnn_dual_path).  State slabs: 0/1 = h/c of lstms.1, 2/3 = h/c of
  *     lstms.3; dim 1 = LSTM layer; dim 2 = c*K + k.
  * bsrnn_forward_chunk      = L consecutive forward_recurrent steps in one call (BASELINE.json
  *     config 3): x_dev [C, 2050, L], state carried causally; L = 1 equals forward_recurrent.

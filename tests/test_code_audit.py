@@ -1,4 +1,4 @@
-"""CPU: audit of the shipped gfx950 code object.  The co-residency hazard (notebook section "co-residency hazard";
+"""CPU: audit of the shipped gfx950 code object.  The co-residency hazard (NOTEBOOK.md R3.4;
 profiles/r03_vpk_hazard.txt): STFT / iSTFT kernels whose butterflies the SLP vectorizer had turned into packed-fp32 code
 (v_pk_add / mul / fma_f32, v_pk_mov_b32) returned whole frames of garbage WHILE WAVES OF ANOTHER KERNEL SHARED THEIR CU (beside
 GEMM / LSTM launches: 4-20 of 20 runs wrong), never alone, and never when their workgroups were made to own the CU (all of its LDS

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU run for the co-residency hazard of the SLP-vectorised STFT / iSTFT kernels (DESIGN notebook): the victim process
+# One GPU run for the co-residency hazard of the SLP-vectorised STFT / iSTFT kernels (NOTEBOOK.md R3.4): the victim process
 # loads a variant build of the library (BSRNN_HIP_LIB), the load process the product build.
 #   bash tools/coresident_variants.sh build/libbsrnn_slp.so build/libbsrnn_slp0.so ...
 export PYTHONPATH=.
