@@ -246,8 +246,11 @@ def train_step_record(args):
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         return {"ms_per_step": d["ms_per_step"], "row_frames_per_s": d["row_frames_per_s"], "phases_ms": d.get("phases_ms"),
+                "graph_ms_per_step": d.get("graph_ms_per_step"), "graph_row_frames_per_s": d.get("graph_row_frames_per_s"),
                 "note": "forward + L1 tri-loss + backward + AdamW of m_dataset.train_infer / train.py:97-115 on the exact-fp32 training kernels, "
-                        "gradients verified against torch.autograd (tests/test_gpu_train.py); separate process"}
+                        "gradients verified against torch.autograd (tests/test_gpu_train.py); separate process; ms_per_step = the loop driven "
+                        "from Python (one launch per kernel), graph_ms_per_step = the same iteration captured once and replayed as one hipGraph "
+                        "(train.GraphedTrainStep)"}
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

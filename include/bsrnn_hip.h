@@ -206,6 +206,15 @@ int  bsrnn_adamw_step_multi(bsrnn_ctx* ctx, float* const* p_dev, const float* co
                             const int64_t* sizes, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
                             float weight_decay, int32_t step, void* stream);
 
+/* The same with the step count and the learning rate in DEVICE memory: state_dev = {float lr, float bc1, float bc2s, int32 step}
+ * (16 bytes; the caller initialises lr and step - the number of steps taken so far -, the call advances step by one in stream
+ * order and derives the bias corrections from it on the device).  Nothing that changes from iteration to iteration travels by
+ * value, so a whole training iteration (train.py:97-115: forward, backward, this call) can be captured once into a hipGraph and
+ * replayed; the learning rate of a schedule is a 4-byte copy into state_dev between replays. */
+int  bsrnn_adamw_step_multi_dev(bsrnn_ctx* ctx, float* const* p_dev, const float* const* g_dev, float* const* m_dev, float* const* v_dev,
+                                const int64_t* sizes, int32_t n_tensors, float* state_dev, float beta1, float beta2, float eps,
+                                float weight_decay, void* stream);
+
 /* ---- the STFT sandwich of the callers --------------------------------------------------
  * bsrnn_stft   = infer.py:29-33 (dup. m_dataset.py:187-190): wave_dev [R, n] ->
  *                x_dev [R, 2050, T], T = 1 + n/1024; periodic Hann 2048, hop 1024,

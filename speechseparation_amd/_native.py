@@ -21,7 +21,7 @@ SYMBOLS = [
     "bsrnn_stage_name", "bsrnn_stage_times", "bsrnn_dev_alloc", "bsrnn_dev_free", "bsrnn_copy_h2d", "bsrnn_copy_d2h",
     "bsrnn_sync", "bsrnn_evaluate", "bsrnn_io_count", "bsrnn_io_info", "bsrnn_mlp_fused",
     "bsrnn_lstm_train_forward", "bsrnn_lstm_train_backward", "bsrnn_linear_train_forward", "bsrnn_linear_train_backward",
-    "bsrnn_istft_backward", "bsrnn_adamw_step", "bsrnn_adamw_step_multi",
+    "bsrnn_istft_backward", "bsrnn_adamw_step", "bsrnn_adamw_step_multi", "bsrnn_adamw_step_multi_dev",
     "bsrnn_linear_group_train_forward", "bsrnn_linear_group_train_backward",
     "bsrnn_set_range_policy", "bsrnn_get_range_policy",
 ]
@@ -76,6 +76,7 @@ def _load():
         "bsrnn_linear_group_train_forward": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
         "bsrnn_linear_group_train_backward": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
         "bsrnn_adamw_step_multi": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
+        "bsrnn_adamw_step_multi_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
         "bsrnn_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
         "bsrnn_separate": (C.c_int, [vp, vp, vp, i32, i64, vp]),
         "bsrnn_stream_create": (C.c_int, [vp, i32, C.POINTER(vp)]),

@@ -1419,21 +1419,24 @@ int bsrnn_adamw_step(bsrnn_ctx* c, float* p, const float* g, float* m, float* v,
     return 0;
 }
 
-int bsrnn_adamw_step_multi(bsrnn_ctx* c, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* sizes,
-                           int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream)
+static int adamw_multi(bsrnn_ctx* c, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* sizes,
+                       int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float* state,
+                       void* stream, const char* who)
 {
     if (!c) return fail(BSRNN_EARG, "null context");
     if (c->device < 0 || c->zombie) return fail(BSRNN_ESTATE, "context cannot compute (host-only or destroyed)");
     HIP_TRY(hipSetDevice(c->device));
-    if (!p || !g || !m || !v || !sizes || n_tensors < 1 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
-        return fail(BSRNN_EARG, "bsrnn_adamw_step_multi: bad arguments (n_tensors=%d step=%d)", n_tensors, step);
+    if (!p || !g || !m || !v || !sizes || n_tensors < 1 || (!state && step < 1) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
+        return fail(BSRNN_EARG, "%s: bad arguments (n_tensors=%d step=%d)", who, n_tensors, step);
     for (int i = 0; i < n_tensors; ++i)
-        if (!p[i] || !g[i] || !m[i] || !v[i] || sizes[i] < 0) return fail(BSRNN_EARG, "bsrnn_adamw_step_multi: tensor %d: null pointer or negative size", i);
+        if (!p[i] || !g[i] || !m[i] || !v[i] || sizes[i] < 0) return fail(BSRNN_EARG, "%s: tensor %d: null pointer or negative size", who, i);
     for (int i = 0; i < n_tensors; ++i)
-        if (sizes[i] >= ((int64_t)1 << 31) - 1024) return fail(BSRNN_EARG, "bsrnn_adamw_step_multi: tensor %d has %lld elements (limit 2^31)", i, (long long)sizes[i]);
+        if (sizes[i] >= ((int64_t)1 << 31) - 1024) return fail(BSRNN_EARG, "%s: tensor %d has %lld elements (limit 2^31)", who, i, (long long)sizes[i]);
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    double bc1 = 1.0, bc2 = 1.0;
+    if (state) launch_adamw_tick(state, beta1, beta2, s);
+    else { bc1 = 1.0 - pow((double)beta1, step); bc2 = 1.0 - pow((double)beta2, step); }
     for (int i0 = 0; i0 < n_tensors; i0 += ADAM_GROUP) {
         AdamGroup a;
         a.count = std::min(ADAM_GROUP, n_tensors - i0);
@@ -1443,10 +1446,23 @@ int bsrnn_adamw_step_multi(bsrnn_ctx* c, float* const* p, const float* const* g,
             a.n[j] = (int)sizes[i0 + j];
             a.first_block[j + 1] = a.first_block[j] + (a.n[j] + 1023) / 1024;
         }
-        launch_adamw_group(a, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), s);
+        launch_adamw_group(a, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), s, state);
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int bsrnn_adamw_step_multi(bsrnn_ctx* c, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* sizes,
+                           int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream)
+{
+    return adamw_multi(c, p, g, m, v, sizes, n_tensors, lr, beta1, beta2, eps, weight_decay, step, nullptr, stream, "bsrnn_adamw_step_multi");
+}
+
+int bsrnn_adamw_step_multi_dev(bsrnn_ctx* c, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* sizes,
+                               int32_t n_tensors, float* state_dev, float beta1, float beta2, float eps, float weight_decay, void* stream)
+{
+    if (!state_dev) return fail(BSRNN_EARG, "bsrnn_adamw_step_multi_dev: null optimizer state");
+    return adamw_multi(c, p, g, m, v, sizes, n_tensors, 0.f, beta1, beta2, eps, weight_decay, 0, state_dev, stream, "bsrnn_adamw_step_multi_dev");
 }
 
 int bsrnn_linear_train_forward(bsrnn_ctx* c, const float* x, int32_t ldx, const float* w, const float* b, float* y, int32_t ldy,

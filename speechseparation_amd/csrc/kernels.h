@@ -189,7 +189,10 @@ struct AdamGroup {
     int first_block[ADAM_GROUP + 1];    // prefix sums of ceil(n / 1024)
     int count;
 };
-void launch_adamw_group(const AdamGroup& a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, hipStream_t stream);
+// state != nullptr: {lr, bc1, bc2s, step(int32)} in device memory override the by-value arguments (launch_adamw_tick advances it)
+void launch_adamw_group(const AdamGroup& a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, hipStream_t stream,
+                        const float* state = nullptr);
+void launch_adamw_tick(float* state, float b1, float b2, hipStream_t stream);
 // nn.Linear (+ LeakyReLU(0.01)) for a group of layers that share the row count M (the same layer of all bands):
 struct LinearJob {
     const float* x; int ldx;        // [M][K], row stride ldx

@@ -355,8 +355,12 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 // many tensors per launch: the pointers travel in the kernel arguments (copied at launch: nothing to keep alive, no table to
 // update in stream order); block b belongs to the tensor t with first_block[t] <= b < first_block[t + 1], 1024 elements per block
-__global__ __launch_bounds__(256) void adamw_group_kernel(AdamGroup a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s)
+// state (optional): {lr, bc1, bc2s, step} in device memory, written by adamw_tick_kernel in stream order - a captured launch
+// (hipGraph replay of a whole training iteration) then sees the step count and the learning rate of the replay, not of the capture.
+__global__ __launch_bounds__(256) void adamw_group_kernel(AdamGroup a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                                                          const float* __restrict__ state)
 {
+    if (state) { lr = state[0]; bc1 = state[1]; bc2s = state[2]; }
     int ti = 0;
     while (ti + 1 < a.count && (int)blockIdx.x >= a.first_block[ti + 1]) ++ti;
     float* p = a.p[ti]; const float* g = a.g[ti]; float* m = a.m[ti]; float* v = a.v[ti];
@@ -373,10 +377,25 @@ __global__ __launch_bounds__(256) void adamw_group_kernel(AdamGroup a, float lr,
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
-void launch_adamw_group(const AdamGroup& a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, hipStream_t s)
+void launch_adamw_group(const AdamGroup& a, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s, hipStream_t s,
+                        const float* state)
 {
     if (a.count <= 0 || a.first_block[a.count] <= 0) return;
-    hipLaunchKernelGGL(adamw_group_kernel, dim3(a.first_block[a.count]), dim3(256), 0, s, a, lr, b1, b2, eps, wd, bc1, bc2s);
+    hipLaunchKernelGGL(adamw_group_kernel, dim3(a.first_block[a.count]), dim3(256), 0, s, a, lr, b1, b2, eps, wd, bc1, bc2s, state);
+}
+// step += 1; bc1 = 1 - b1^step, bc2s = sqrt(1 - b2^step) (double, as the host path computes them)
+__global__ void adamw_tick_kernel(float* state, float b1, float b2)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    int* step = reinterpret_cast<int*>(state + 3);
+    const int t = *step + 1;
+    *step = t;
+    state[1] = (float)(1.0 - pow((double)b1, (double)t));
+    state[2] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+void launch_adamw_tick(float* state, float b1, float b2, hipStream_t s)
+{
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, s, state, b1, b2);
 }
 
 void launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,

@@ -326,7 +326,12 @@ class AdamW:
     'exp_avg_sq'}}, 'param_groups': [...]}, indices in `model.parameters()` order with the zero-size parameters counted - so the
     reference's `optimizer.pth` / `optimizer-always.pth` (train.py:169-172) and the files written here interchange."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
+        """capturable (as torch.optim.AdamW's flag): the step count and the learning rate live in device memory
+        (bsrnn_adamw_step_multi_dev), so that step() can be captured into a hipGraph with the rest of an iteration (GraphedTrainStep);
+        every parameter must then have a gradient in every step (one step count for all, as in the reference's loop)."""
+        self.capturable = bool(capturable)
+        self._state_dev = None                              # capturable: {lr, bc1, bc2s, step} on the device
         self.all_params = list(params)                      # model.parameters() order = the indices of torch's state_dict
         self.slot = [i for i, p in enumerate(self.all_params) if p.numel() > 0]      # the ones the kernel updates
         self.params = [self.all_params[i] for i in self.slot]
@@ -354,6 +359,9 @@ class AdamW:
         if not idx_all:
             return
         dev = self.params[idx_all[0]].device
+        if self.capturable:
+            self._step_capturable(idx_all, dev)
+            return
         for t in sorted({self.steps[self.slot[j]] for j in idx_all}):
             idx = [j for j in idx_all if self.steps[self.slot[j]] == t]
             grads = [_f32c(self.params[j].grad) for j in idx]
@@ -369,6 +377,55 @@ class AdamW:
                                                           self.eps, self.weight_decay, t, _s(dev)))
         for j in idx_all:  # the kernel wrote the parameters behind torch's back: bump their version counters (BSRNN re-uploads
             torch.autograd.graph.increment_version(self.params[j])      # its inference weights when a version changes)
+
+    def _device_state(self, dev, steps_so_far):
+        """{lr, bc1, bc2s, step} for bsrnn_adamw_step_multi_dev; (re)written whenever the host-side step count or lr was changed
+        behind it (load_state_dict, set_lr)."""
+        if self._state_dev is None or self._state_dev.device != dev:
+            self._state_dev = torch.zeros(4, device=dev)
+            self._state_host = None
+        want = (float(self.lr), int(steps_so_far))
+        if self._state_host != want:
+            self._state_dev[0] = want[0]
+            self._state_dev.view(torch.int32)[3] = want[1]
+            self._state_host = want
+        return self._state_dev
+
+    def set_lr(self, lr):
+        """Learning rate of the next steps (a schedule); in capturable mode a 4-byte write the captured step reads from the device."""
+        self.lr = float(lr)
+        if self._state_dev is not None:
+            self._state_dev[0] = self.lr
+            self._state_host = (self.lr, self._state_host[1]) if self._state_host else None
+
+    def _step_capturable(self, idx_all, dev):
+        if len(idx_all) != len(self.params) or len({self.steps[i] for i in self.slot}) != 1:
+            raise RuntimeError("capturable AdamW: every parameter needs a gradient in every step (one step count for all)")
+        t = self.steps[self.slot[0]]                         # already counted for this step
+        state = self._device_state(dev, t - 1)
+        n = len(idx_all)
+        key = ("dev",) + tuple(idx_all)
+        if key not in self._cache:
+            arr = lambda ts: (ctypes.c_void_p * n)(*[ts[j].data_ptr() for j in idx_all])      # noqa: E731
+            self._cache = {key: (arr(self.params), arr(self.m), arr(self.v), (ctypes.c_int64 * n)(*[self.params[j].numel() for j in idx_all]))}
+        ap, am, av, sizes = self._cache[key]
+        grads = [_f32c(self.params[j].grad) for j in idx_all]
+        ag = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+        with torch.cuda.device(dev):
+            _native.check(_lib.bsrnn_adamw_step_multi_dev(_context(dev), ap, ag, am, av, sizes, n, _p(state), self.betas[0], self.betas[1],
+                                                          self.eps, self.weight_decay, _s(dev)))
+        self._state_host = (self._state_host[0], t)          # the device counted this step
+        for j in idx_all:
+            torch.autograd.graph.increment_version(self.params[j])
+
+    def note_replayed_step(self):
+        """Book-keeping of one replay of a captured step(): the device advanced its own step count and wrote the parameters."""
+        for i in self.slot:
+            self.steps[i] += 1
+        if self._state_host:
+            self._state_host = (self._state_host[0], self._state_host[1] + 1)
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
 
     def _group_template(self):
         """param_groups[0] with every key this torch version's AdamW carries (its load_state_dict adopts the saved group as is)."""
@@ -422,6 +479,8 @@ class AdamW:
                 self.m[pos[i]].copy_(st["exp_avg"])
                 self.v[pos[i]].copy_(st["exp_avg_sq"])
         self._cache = {}
+        if self._state_dev is not None:                      # capturable: the device's step count follows the loaded one
+            self._device_state(self._state_dev.device, self.t)
 
 
 def train_step(model, optimizer, mix, speech, group=None, loss_sdr=False):
@@ -437,3 +496,71 @@ def train_step(model, optimizer, mix, speech, group=None, loss_sdr=False):
     optimizer.step()
     optimizer.zero_grad()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """`train_step` with the whole iteration - STFTs, forward, loss, backward, AdamW, zero_grad - captured ONCE into a hipGraph and
+    replayed: one graph launch per iteration instead of ~ 400 kernel launches driven by Python and autograd (the reference's own
+    configuration, batch_size 1 = two rows, is bound by exactly that).  Fixed clip shape [rows, samples]; single process (the
+    data-parallel all-reduce is not captured: use train_step under torch.distributed); the optimizer must be
+    AdamW(..., capturable=True).  The first `warmup` calls run eagerly on the capture stream (they are ordinary training steps
+    and size the library's scratch buffers, which must not grow during capture); the next call captures, every call from then on
+    replays.  Results are those of train_step (same kernels, same order).
+
+        step = GraphedTrainStep(model, optimizer, rows=2, samples=128000)
+        for mix, speech in loader: loss = step(mix, speech)
+    """
+
+    def __init__(self, model, optimizer, rows, samples, loss_sdr=False, warmup=2):
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedTrainStep needs AdamW(..., capturable=True): the step count must live on the device")
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            raise RuntimeError("GraphedTrainStep is single-process; use train_step under torch.distributed")
+        self.model, self.optimizer, self.loss_sdr = model, optimizer, bool(loss_sdr)
+        self.device = next(p for p in model.parameters() if p.numel() > 0).device
+        if self.device.type != "cuda":
+            raise ValueError("the training kernels run on the GPU: move the model to a cuda device first")
+        self.mix = torch.zeros((rows, samples), device=self.device)
+        self.speech = torch.zeros((rows, samples), device=self.device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.warmup, self.calls = max(1, int(warmup)), 0     # at least one eager step: scratch and workspaces must exist before capture
+        self.graph, self.loss, self.sdr = None, None, None
+        self.last_sdr = None                                  # `sdr` of train_infer for the last clip (train.py prints its epoch mean)
+
+    def _iteration(self):
+        loss, x_time = train_loss(self.model, self.mix, self.speech)
+        s = sdr(x_time, self.speech[:, :x_time.shape[1]])
+        (-s if self.loss_sdr else loss).backward()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return loss.detach(), s.detach()
+
+    def __call__(self, mix, speech):
+        if tuple(mix.shape) != tuple(self.mix.shape) or tuple(speech.shape) != tuple(self.speech.shape):
+            raise ValueError("GraphedTrainStep was built for clips of shape %s" % (tuple(self.mix.shape),))
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.mix.copy_(mix, non_blocking=True)
+            self.speech.copy_(speech, non_blocking=True)
+            if self.graph is None and self.calls < self.warmup:
+                out, self.last_sdr = (t.clone() for t in self._iteration())
+            else:
+                if self.graph is None:
+                    self.optimizer._device_state(self.device, self.optimizer.t)    # exists and is current BEFORE capture (no captured writes)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.stream):
+                        self.loss, self.sdr = self._iteration()
+                    self.graph = g
+                    # capture ran the Python side of optimizer.step() once without executing anything: take its count back,
+                    # the replay below is the step
+                    for i in self.optimizer.slot:
+                        self.optimizer.steps[i] -= 1
+                    self.optimizer._state_host = (self.optimizer._state_host[0], self.optimizer._state_host[1] - 1)
+                self.graph.replay()
+                self.optimizer.note_replayed_step()
+                out, self.last_sdr = self.loss.clone(), self.sdr.clone()
+        self.calls += 1
+        cur.wait_stream(self.stream)
+        return out

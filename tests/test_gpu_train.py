@@ -273,6 +273,54 @@ def test_three_train_steps_follow_torch_adamw():
     assert worst[0] < 2e-3
 
 
+def test_graphed_train_step_replays_the_eager_iterations():
+    """train.GraphedTrainStep: the iteration of train.py:97-115 captured once into a hipGraph (STFTs, forward, loss, backward, AdamW with
+    its step count on the device, zero_grad) and replayed, against train.train_step driven from Python: five iterations with a
+    different clip each (1 eager warm-up, capture + replay, three replays), then a learning-rate change through set_lr and one more.
+    Same kernels in the same order: losses and parameters agree to fp32 rounding of the bias corrections (device pow vs host pow);
+    the optimizer's torch-format state_dict carries the step count of the replays."""
+    from speechseparation_amd import train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    sd = weights.synth_state_dict(None, seed=0)
+    n = 6 * 1024
+    clips = [(torch.from_numpy(weights.synth_waveform(2, n, seed=40 + i)).cuda(), torch.from_numpy(weights.synth_waveform(2, n, seed=60 + i)).cuda())
+             for i in range(6)]
+
+    def fresh(capturable):
+        m = BSRNN().train()
+        m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+        m = m.to("cuda:0")
+        return m, train.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-2, capturable=capturable)
+
+    m1, o1 = fresh(False)
+    eager = [float(train.train_step(m1, o1, a, b)) for a, b in clips[:5]]
+    o1.set_lr(3e-4)
+    eager.append(float(train.train_step(m1, o1, *clips[5])))
+
+    m2, o2 = fresh(True)
+    step = train.GraphedTrainStep(m2, o2, 2, n, warmup=1)
+    graphed = [float(step(a, b)) for a, b in clips[:5]]
+    assert step.graph is not None and step.calls == 5
+    o2.set_lr(3e-4)
+    graphed.append(float(step(*clips[5])))
+    print("eager  ", eager)
+    print("graphed", graphed)
+    for a, b in zip(graphed, eager):
+        assert abs(a - b) <= 2e-6 * abs(b), (graphed, eager)
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    worst = max((float((p1[k] - p2[k]).abs().max()), k) for k in p1 if p1[k].numel())
+    print("largest parameter difference eager vs graphed after six steps: %.2e (%s)" % worst)
+    assert worst[0] < 2e-6
+    s1, s2 = o1.state_dict(), o2.state_dict()
+    assert set(s1["state"]) == set(s2["state"])
+    assert all(float(s2["state"][i]["step"]) == 6.0 for i in s2["state"])
+    assert s2["param_groups"][0]["lr"] == pytest.approx(3e-4)
+    with pytest.raises(ValueError):
+        step(clips[0][0][:, :4096], clips[0][1][:, :4096])                  # another clip shape than the captured one
+    with pytest.raises(ValueError):
+        train.GraphedTrainStep(m1, o1, 2, n)                                # optimizer without the device-side step count
+
+
 @pytest.mark.parametrize("leaky", [True, False])
 def test_grouped_linear_matches_autograd(leaky):
     """The same layer of several bands in grouped launches (bsrnn_linear_group_train_*): different widths, inputs that are column
@@ -442,6 +490,40 @@ def test_train_entry_point_runs_epochs_validates_and_checkpoints(tmp_path):
     assert p2.returncode == 0, p2.stderr[-2000:]
     resumed = [float(l.split()[3]) for l in p2.stdout.splitlines() if l.startswith("Epoch") and "Loss" in l]
     assert resumed and resumed[0] < losses[0]
+
+
+def test_train_entry_point_with_graph_replay_prints_the_same_epochs(tmp_path):
+    """train.py --graph (every iteration one hipGraph replay) against the same command line launch by launch: the epoch losses /
+    SDRs and the validation figures (inference path on the weights the replays wrote) agree; --resume continues from the
+    optimizer's saved step count."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, PYTHONPATH=REPO)
+    runs = {}
+    for tag, extra in (("eager", []), ("graph", ["--graph"])):
+        out = tmp_path / tag
+        out.mkdir()
+        cmd = [sys.executable, os.path.join(REPO, "train.py"), "--synthetic", "4", "--seconds", "1", "--epochs", "2", "--batch_size", "1",
+               "--synthetic-weights", "0", "--outdir", str(out)] + extra
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        ep = [(float(l.split()[3]), float(l.split()[5])) for l in p.stdout.splitlines() if l.startswith("Epoch") and "Loss" in l]
+        va = [(float(l.split()[2]), float(l.split()[5])) for l in p.stdout.splitlines() if l.startswith("Validation Loss")]
+        runs[tag] = (ep, va, cmd)
+        print(tag, ep, va)
+    (e_ep, e_va, _), (g_ep, g_va, g_cmd) = runs["eager"], runs["graph"]
+    assert len(g_ep) == 2 and len(g_va) == 2
+    for a, b in zip(g_ep + g_va, e_ep + e_va):
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-4 * max(1.0, abs(b[1])), (runs["graph"][:2], runs["eager"][:2])
+    before = {float(st["step"]) for st in torch.load(tmp_path / "graph" / "optimizer.pth", weights_only=True)["state"].values()}
+    assert before in ({4.0}, {8.0})                               # the best epoch's optimizer: 4 clips per epoch
+    p2 = subprocess.run(g_cmd + ["--resume", "--epochs", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    resumed = [float(l.split()[3]) for l in p2.stdout.splitlines() if l.startswith("Epoch") and "Loss" in l]
+    assert resumed and resumed[0] < g_ep[0][0]
+    after = {float(st["step"]) for st in torch.load(tmp_path / "graph" / "optimizer-always.pth", weights_only=True)["state"].values()}
+    assert after == {before.pop() + 4.0}                          # the device-side step count continued from the loaded one
 
 
 def test_training_gradients_on_the_41_band_table():

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement (train.GraphedTrainStep)")
     a = ap.parse_args()
     n = int(a.seconds * 16000)
     sd = weights.synth_state_dict(None, seed=0)
@@ -58,6 +59,24 @@ def main():
     T = 1 + n // 1024
     line = {"config": "train step (train.py:97-115, batch_size 1): %d rows x %.0f s @16 kHz (T=%d), exact-fp32 training kernels" % (a.rows, a.seconds, T),
             "ms_per_step": round(ms, 2), "row_frames_per_s": round(a.rows * T / (ms * 1e-3), 1), "loss_after": round(float(loss), 5), "phases_ms": ph}
+    if not a.no_graph:
+        # the same iteration as one hipGraph replay (fresh model and optimizer, same start: the losses must agree with the eager run's)
+        m2 = BSRNN().train()
+        m2.load_state_dict({k: torch.from_numpy(np.array(v, copy=True)) for k, v in sd.items()})
+        m2 = m2.to("cuda:0")
+        opt2 = train.AdamW(m2.parameters(), lr=1e-3, weight_decay=1e-2, capturable=True)
+        step = train.GraphedTrainStep(m2, opt2, a.rows, n, warmup=1)
+        for _ in range(2):                                   # one eager step, then capture + first replay
+            step(mg, sg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            lg = step(mg, sg)
+        torch.cuda.synchronize()
+        gms = 1e3 * (time.perf_counter() - t0) / a.steps
+        line["graph_ms_per_step"] = round(gms, 2)
+        line["graph_row_frames_per_s"] = round(a.rows * T / (gms * 1e-3), 1)
+        line["graph_loss_after"] = round(float(lg), 5)       # after 2 + steps iterations, as loss_after
     if not a.no_cpu:
         from oracle.bsrnn_torch_cpu import TorchCpuBSRNN   # checker / CPU baseline only
         ref = TorchCpuBSRNN(sd, spec.generate_bandsplits()[0])

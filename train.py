@@ -68,6 +68,8 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="N synthetic training clips (and N // 4 + 1 for validation)")
     ap.add_argument("--seconds", type=float, default=4.0, help="length of the synthetic clips")
     ap.add_argument("--synthetic-weights", type=int, default=None, metavar="SEED", help="initial weights from the seeded generator instead of torch's init")
+    ap.add_argument("--graph", action="store_true", help="replay each iteration as one hipGraph (speechseparation_amd.train.GraphedTrainStep): "
+                    "single process, --batch_size 1, one graph per clip length (at most 4 lengths, other clips run launch by launch)")
     ap.add_argument("--device", type=str, default=None)
     ap.add_argument("--outdir", type=str, default=".")
     args = ap.parse_args(argv)
@@ -101,7 +103,11 @@ def main(argv=None):
     if args.resume:
         model.load_state_dict(torch.load(os.path.join(args.outdir, "model.pth"), weights_only=True))
     model = model.to(device)
-    optimizer = hip_train.AdamW(model.parameters(), lr=0.001, weight_decay=0.01)
+    use_graph = args.graph and world == 1 and args.batch_size == 1
+    if args.graph and not use_graph and rank == 0:
+        print("--graph needs a single process and --batch_size 1: running launch by launch")
+    optimizer = hip_train.AdamW(model.parameters(), lr=0.001, weight_decay=0.01, capturable=use_graph)
+    graphs = {}                                                  # clip shape -> GraphedTrainStep
     if args.resume and os.path.exists(os.path.join(args.outdir, "optimizer.pth")):
         optimizer.load_state_dict(torch.load(os.path.join(args.outdir, "optimizer.pth"), weights_only=True))
 
@@ -115,6 +121,15 @@ def main(argv=None):
         epoch_loss, epoch_sdr, batch_i = 0.0, 0.0, 0
         for idx in order:
             mix, speech = load_pair(train_set[idx], device)
+            if use_graph and (tuple(mix.shape) in graphs or len(graphs) < 4):
+                if tuple(mix.shape) not in graphs:
+                    graphs[tuple(mix.shape)] = hip_train.GraphedTrainStep(model, optimizer, mix.shape[0], mix.shape[1], loss_sdr=args.loss_sdr)
+                step = graphs[tuple(mix.shape)]
+                loss = step(mix, speech)                         # loss, backward, optimizer step, zero_grad: one graph launch
+                batch_i += 1
+                epoch_loss += float(loss)
+                epoch_sdr += float(step.last_sdr)
+                continue
             loss, x_time = hip_train.train_loss(model, mix, speech)
             sdr = hip_train.sdr(x_time, speech[:, :x_time.shape[1]])
             (-sdr if args.loss_sdr else loss).backward()
