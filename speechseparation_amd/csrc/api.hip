@@ -467,13 +467,18 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
                                     c->bandFc16[blk], c->bandFcB[blk], M, K, c->d_range, s);
             break;
         }
-        launch_band_lstm(p.Z0, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
-        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);
+        // parts flow (band_fc_in_parts()): block 0 reads Z0 and its time block writes Z1, block 1 reads Z1 and its time block writes
+        // Z0 - the block's fc + residual are formed inside the two launches around them (kernels.h), MS_BANDFC does not exist
+        const bool parts = band_fc_in_parts();
+        const float* zi = parts && blk ? p.Z1 : p.Z0;
+        launch_band_lstm(zi, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
+        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s,
+                         parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr);
         break;
     }
     case MS_BANDFC0: case MS_BANDFC1: {
         const int blk = stage == MS_BANDFC1;
-        if (band_block_is_small(M, K)) break;     // done inside the band launch
+        if (band_block_is_small(M, K) || band_fc_in_parts()) break;     // done inside the band launch / inside the launches around it
         StageScope sc(c, ST_BAND_FC, s);
         gemm_slot(c, BLK_FC0 + 2 * blk, p.HB1, 2 * HID, p.Z1, HID, p.Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
         break;
@@ -483,6 +488,13 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         StageScope sc(c, ST_TIME_LSTM, s);
         // fp16x2 mode: the launch also computes the block's fc + residual (out = fc(h1) + Z1 -> Z0); otherwise it writes h1
         const bool fused = time_lstm_fuses_fc();
+        if (band_fc_in_parts() && !band_block_is_small(M, K)) {
+            launch_time_lstm(blk ? p.Z1 : p.Z0, blk ? p.Z0 : p.Z1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
+                             p.state_in ? p.state_in + blk * p.state_slab : nullptr,
+                             p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, c->d_range, s,
+                             c->timeFc16[blk], c->timeFcB[blk], p.HB1);
+            break;
+        }
         launch_time_lstm(p.Z1, fused ? p.Z0 : p.H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
                          p.state_in ? p.state_in + blk * p.state_slab : nullptr,
                          p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, c->d_range, s,
@@ -1325,6 +1337,15 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
         if (band_block_is_small(M, K)) {
             launch_band_block_small(c->Z0, c->Z1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1],
                                     c->bandFc16[blk], c->bandFcB[blk], M, K, c->d_range, s);
+        } else if (band_fc_in_parts()) {           // the block's fc + residual inside the launches around it (run_stage, kernels.h)
+            float* zi = blk ? c->Z1 : c->Z0;
+            float* zo = blk ? c->Z0 : c->Z1;
+            launch_band_lstm(zi, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
+            launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s,
+                             c->bandFc16[blk], c->bandFcB[blk]);
+            launch_time_lstm(zi, zo, c->timeW[blk], c->timeW16[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
+                             state_out ? state_out + blk * slab : nullptr, C, T, K, c->d_range, s, c->timeFc16[blk], c->timeFcB[blk], c->HB1);
+            continue;
         } else {
             launch_band_lstm(c->Z0, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
             launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);

@@ -124,8 +124,13 @@ void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 //   wpk  packed [2 dir][4 wave][(IN+64)/4 step][4 gate][64 lane], bias [2][256]
 //   wpk16 (LSTM_FP16X2): the same matrix as two fp16 pieces in the f16 MFMA's B-operand order,
 //         [2 dir][4 wave][(IN+64)/32 blk][4 gate][2 piece][64 lane][8]
+//   fc16 / fcb (LSTM_FP16X2, IN = 128, optional): the block's fc (128 -> 64) as launch_band_block_small takes it.  When given, hout
+//        receives, instead of h, the two directions' SHARES of fc(h): hout[n][t][dir * 64 + f] = sum_k W_fc[f][dir * 64 + k] h_dir[n][t][k]
+//        (+ b[f] in the forward half); the time-axis launch adds the halves and the residual (`part` of launch_time_lstm), so the
+//        block's fc launch disappears.  band_fc_in_parts() says whether api.hip runs the blocks that way.
 void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      int N, int L, int IN, int* range_flag, hipStream_t stream);
+                      int N, int L, int IN, int* range_flag, hipStream_t stream, const void* fc16 = nullptr, const float* fcb = nullptr);
+bool band_fc_in_parts();
 // The whole band-axis block (both layers, both directions, fc + residual) of a few sequences in one workgroup: the streaming
 // step's N = C frame rows.  w0pk16 / w1pk16 / bias0 / bias1 are launch_band_lstm's arguments of the two layers; fc16 the block's
 // fc (128 -> 64) as fp16x2 B fragments [4 tile][4 blk][2 piece][64 lane][8], fcb its bias.  zout = fc(h1) + b + zin.
@@ -142,9 +147,11 @@ int lstm_mode();
 //   fc16 / fcb (LSTM_FP16X2, optional): the block's trailing fc (bsrnn.py:84) as two fp16 pieces in B-operand order,
 //         [4 wave][2 blk][2 piece][64 lane][8], and its bias [64].  When time_lstm_fuses_fc() and both are given, the launch
 //         writes the BLOCK's output fc(h1) + b + zin to hout (h1 never leaves the chip); otherwise hout = h1.
+//   part (with fc16 / fcb only, optional) [R][T][K][2][64]: the block's input is zin + part[.., 0, :] + part[.., 1, :] instead of zin
+//         (the shares of the preceding band block's fc, see launch_band_lstm); hout must then be a different buffer than zin.
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,
-                      const void* fc16 = nullptr, const float* fcb = nullptr);
+                      const void* fc16 = nullptr, const float* fcb = nullptr, const float* part = nullptr);
 bool time_lstm_fuses_fc();
 
 // ------------------------------------------------------------------ training step, part 1: recurrent layers (lstm_train.hip)

@@ -20,6 +20,9 @@
 #ifndef BAND_NLDS
 #define BAND_NLDS 2                 // second-piece weight blocks of the 128-input layer kept in LDS (3: 226 VGPRs, 2: 242, 1: 254)
 #endif
+#ifndef PART_DBG
+#define PART_DBG 0                  // measurement only (tools/band_parts_check.hip): 1 no fc MFMAs, 2 no fclds array (fragments = garbage), 4 no tail
+#endif
 #ifndef BAND_NO_PLANES
 #define BAND_NO_PLANES 0            // measurement only: 1 = fp32 instead of fp16 planes between the two band layers (A/B, tools/precision_dual_path.py)
 #endif
@@ -209,11 +212,18 @@ __device__ __forceinline__ void split_h2(float v, _Float16& p0, _Float16& p1)
     p1 = (_Float16)__builtin_fmaf(-(float)p0, 2048.f, v * 2048.f);      // = 2048 (v - p0), exact before the conversion: one v_fma_mixlo_f16
 }
 
-template <int IN, bool TRACE = false>
+// PART (layer 1 only): instead of h the launch writes THIS DIRECTION'S SHARE OF THE BLOCK'S fc (bsrnn.py:84: fc(h_fwd | h_bwd) =
+// W[:, :64] h_fwd + W[:, 64:] h_bwd + b), hout[n][t][dir * 64 + f] = sum_k W_fc[f][dir * 64 + k] h_dir[n][t][k] (+ b[f] in the
+// forward half), and the consumer (the time-axis kernel's staging) adds the two halves and the residual - the grouped-GEMM launch
+// of the block's fc, its 100 MB of traffic and its 18 us are gone.  The product is formed where h_{t} is read back as the next
+// step's B operand anyway: 6 more MFMAs per wave and step on the fragments already in registers, the fc's A fragments from LDS.
+template <int IN, bool TRACE = false, bool PART = false>
 __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __restrict__ xin, float* __restrict__ hout,
                                                               const uint4* __restrict__ wpk, const float* __restrict__ bias,
-                                                              int N, int L, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg)
+                                                              int N, int L, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
+                                                              const uint4* __restrict__ wfc = nullptr, const float* __restrict__ bfc = nullptr)
 {
+    static_assert(!PART || IN == 2 * HID, "the fc share is formed by the second layer");
     // measurement only (TRACE, tools/lstm_h2_trace.hip): 100 MHz stamps per phase, accumulated per wave
     unsigned long long tp[5] = {0, 0, 0, 0, 0}, tq = 0;
     auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) _Float16 hpl[2][2][HID * 16];
     __shared__ __attribute__((aligned(16))) uint4 w2lds[NLDS ? 4 * NLDS * 4 * 64 : 1];
     __shared__ __attribute__((aligned(16))) float bias_lds[4 * HID];         // this direction's b_ih + b_hh, [gate][unit]
+    __shared__ __attribute__((aligned(16))) uint4 fclds[PART && !(PART_DBG & 2) ? 4 * 2 * 2 * 64 : 1];   // fc A fragments [wave][k block][piece][lane]
 
     const int dir = blockIdx.y;
     const int n0 = blockIdx.x * 16;
@@ -254,6 +265,11 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
                 }
     }
     bias_lds[tid] = bias[dir * 256 + tid];
+    if (PART) {
+        // W_fc as [4 tile][4 k block][2 piece][64 lane][8] (api.hip): tile = this wave's 16 output features, k blocks 2 dir + b
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fclds[(PART_DBG & 2) ? 0 : (wave * 4 + i) * 64 + lane] = wfc[((size_t)(wave * 4 + 2 * dir) * 2 + i) * 64 + lane];
+    }
     // The loads above are still in flight when the step loop starts, and the compiler's wait-count bookkeeping merges
     // that state into the loop (it waited for vmcnt(0), i.e. for the x prefetch of the same step, in front of the last
     // recurrent MFMA of every step).  A use of every resident register here makes the waits happen once, up front.
@@ -350,7 +366,19 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
             a0 = n0v; a1 = n1v;
         }
     };
-    auto h_part = [&](int slot) {
+    // PART: the fc share of the h whose fragments are in registers (features 16 wave + 4 q + r of sequence l15, like the gates)
+    v4f fhi = zero4, flo = zero4;
+    v4f fbias = zero4;
+    if (PART && dir == 0) fbias = *reinterpret_cast<const v4f*>(bfc + 16 * wave + 4 * q);
+    auto fc_mfma = [&](const int b, const h8v a0, const h8v a1) {
+        if (PART_DBG & 1) { fhi = fbias; flo = zero4; return; }
+        const h8v f1 = __builtin_bit_cast(h8v, (PART_DBG & 2) ? w2lds[(wave * 4 + 2 * b) * 64 + lane] : fclds[(wave * 4 + 2 * b) * 64 + lane]);
+        const h8v f2 = __builtin_bit_cast(h8v, (PART_DBG & 2) ? w2lds[(wave * 4 + 2 * b + 1) * 64 + lane] : fclds[(wave * 4 + 2 * b + 1) * 64 + lane]);
+        fhi = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, a0, b == 0 ? fbias : fhi, 0, 0, 0);
+        flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, a1, b == 0 ? zero4 : flo, 0, 0, 0);
+        flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f2, a0, flo, 0, 0, 0);
+    };
+    auto h_part = [&](int slot, const bool gates) {
         h8v a0 = *reinterpret_cast<const h8v*>(&hpl[slot][0][frag]);
         h8v a1 = *reinterpret_cast<const h8v*>(&hpl[slot][1][frag]);
 #pragma unroll
@@ -360,8 +388,9 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
                 n0v = *reinterpret_cast<const h8v*>(&hpl[slot][0][(b + 1) * 512 + frag]);
                 n1v = *reinterpret_cast<const h8v*>(&hpl[slot][1][(b + 1) * 512 + frag]);
             }
-            block_mfma(NBX + b, a0, a1);
+            if (gates) block_mfma(NBX + b, a0, a1);
             __builtin_amdgcn_sched_barrier(0);
+            if (PART) { fc_mfma(b, a0, a1); __builtin_amdgcn_sched_barrier(0); }
             a0 = n0v; a1 = n1v;
         }
     };
@@ -381,6 +410,11 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     if (L > 2) xload(tmap(2), xn);
     __syncthreads();
     x_part(0);
+    // Step 0 overwrites slot 0 (x_0 -> x_2) as soon as ITS wave is through h_part and the cell, so every wave must be through
+    // x_part(0) first.  (Missing until round 3: a wave that was late by more than a cell update - its weight loads came from HBM
+    // instead of the Infinity Cache - read x_2 fragments for x_0; seen as rare wrong sequences, run to run, only in launches whose
+    // buffers exceed the cache: 24 576 sequences and more.  tools/band_parts_check.hip.)
+    if (L > 2) __syncthreads();
     stamp(0);
 
     // where this lane's four values of a step go: LDS planes (next step's B operand), global (next layer)
@@ -391,7 +425,9 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         const int t = tmap(step);
         const bool more2 = step + 2 < L;
 
-        h_part((step + 1) & 1);                  // h_{step-1} lives in slot (step - 1) & 1
+        h_part((step + 1) & 1, true);            // h_{step-1} lives in slot (step - 1) & 1
+        if (PART && step > 0 && row_ok && !(BAND_ABL & 2))        // ... and its fc share leaves here
+            *reinterpret_cast<v4f*>(hout + (grow + tmap(step - 1)) * (2 * HID) + dir * HID + 16 * wave + 4 * q) = fhi + flo * (1.f / 2048.f);
         stamp(1);
 
         {   // cell update on 4-vectors (the adds / multiplies become v_pk_*, only the 5 exp + 5 rcp per cell stay scalar)
@@ -418,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
                     _Float16* const hp = reinterpret_cast<_Float16*>(hout) + ((grow + t) * 2) * (2 * HID) + dir * HID + 16 * wave + 4 * q;
                     *reinterpret_cast<h4v*>(hp) = p0;
                     *reinterpret_cast<h4v*>(hp + 2 * HID) = p1;
-                } else {
+                } else if (!PART) {
                     *reinterpret_cast<v4f*>(hout + (grow + t) * (2 * HID) + dir * HID + 16 * wave + 4 * q) = hv4;
                 }
             }
@@ -430,6 +466,11 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
         if (!(BAND_ABL & 8)) __syncthreads();
         stamp(4);
     }
+    if (PART && !(PART_DBG & 4)) {               // the last step's h (published before the loop's last barrier)
+        h_part((L - 1) & 1, false);
+        if (row_ok && !(BAND_ABL & 2))
+            *reinterpret_cast<v4f*>(hout + (grow + tmap(L - 1)) * (2 * HID) + dir * HID + 16 * wave + 4 * q) = fhi + flo * (1.f / 2048.f);
+    }
     if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
     if (TRACE && lane == 0 && blockIdx.x < 4 && blockIdx.y == 0) {
         unsigned long long* d = dbg + (blockIdx.x * 4 + wave) * 5;
@@ -438,12 +479,25 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     }
 }
 
+// BSRNN_BAND_FC = part (default: the second band layer writes the two directions' shares of the block's fc, the time-axis launch adds
+// them and the residual while it stages its input) | gemm (the block's fc + residual as a grouped-GEMM launch, as in rounds 1-2)
+bool band_fc_in_parts()
+{
+    static const bool on = [] { const char* e = getenv("BSRNN_BAND_FC"); return !(e && !strcmp(e, "gemm")); }();
+    return on && lstm_mode() == LSTM_FP16X2 && !force_f32() && time_lstm_fuses_fc();
+}
+
 void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      int N, int L, int IN, int* range_flag, hipStream_t stream)
+                      int N, int L, int IN, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb)
 {
     if (N <= 0 || L <= 0) return;
     dim3 grid((N + 15) / 16, 2), block(256);
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
+        if (IN == 128 && fc16) {
+            hipLaunchKernelGGL((band_lstm_h2_kernel<128, false, true>), grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, range_flag,
+                               (unsigned long long*)nullptr, (const uint4*)fc16, fcb);
+            return;
+        }
         if (IN == 64)
             hipLaunchKernelGGL(band_lstm_h2_kernel<64>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, range_flag, (unsigned long long*)nullptr);
         else
@@ -915,12 +969,16 @@ __device__ __forceinline__ void lds_arrive(int* cnt, int lane)
     asm volatile("" ::: "memory");
 }
 
-template <bool FUSE, bool TRACE = false>
+// PART: the block's input is not zin alone but zin + part[.., 0:64] + part[.., 64:128] - the residual and the two directions' shares
+// of the preceding band block's fc (band_lstm_h2_kernel<128, ., true> wrote them, [sequence-position][2][64]); the staging wave adds
+// them on the way into LDS and the fc wave adds the same three rows as ITS residual, so that block's fc launch does not exist.
+template <bool FUSE, bool TRACE = false, bool PART = false>
 __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __restrict__ zin, float* __restrict__ hout,
                                                              const uint4* __restrict__ wpk, const float* __restrict__ bias,
                                                              const uint4* __restrict__ wfc, const float* __restrict__ bfc,
                                                              const float* __restrict__ state_in, float* __restrict__ state_out,
-                                                             int R, int T, int K, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg)
+                                                             int R, int T, int K, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
+                                                             const float* __restrict__ part = nullptr)
 {
     unsigned long long tp[4] = {0, 0, 0, 0}, tq = 0;          // measurement only
     auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
@@ -1114,18 +1172,28 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                 xs_base = ((size_t)(ni / K) * T * K + (ni % K)) * HID + 4 * xs_c4;
             }
             float amax = 0.f;                    // range guard
-            auto chunk_load = [&](int chunk, float4 (&v)[2]) {
+            struct XRows { float4 z[2], pf[PART ? 2 : 1], pb[PART ? 2 : 1]; };
+            auto chunk_load = [&](int chunk, XRows& v) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     int t = chunk * TCH + xs_t + 4 * hf;
                     t = t < T ? t : T - 1;
-                    v[hf] = *reinterpret_cast<const float4*>(zin + xs_base + (size_t)t * tstride);
+                    v.z[hf] = *reinterpret_cast<const float4*>(zin + xs_base + (size_t)t * tstride);
+                    if (PART) {
+                        const float* pp = part + 2 * (xs_base - 4 * xs_c4 + (size_t)t * tstride) + 4 * xs_c4;
+                        v.pf[hf] = *reinterpret_cast<const float4*>(pp);
+                        v.pb[hf] = *reinterpret_cast<const float4*>(pp + HID);
+                    }
                 }
             };
-            auto chunk_store = [&](int chunk, const float4 (&v)[2]) {
+            auto chunk_store = [&](int chunk, const XRows& v) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const float f[4] = {v[hf].x, v[hf].y, v[hf].z, v[hf].w};
+                    float f[4] = {v.z[hf].x, v.z[hf].y, v.z[hf].z, v.z[hf].w};
+                    if (PART) {
+                        f[0] = (f[0] + v.pf[hf].x) + v.pb[hf].x; f[1] = (f[1] + v.pf[hf].y) + v.pb[hf].y;
+                        f[2] = (f[2] + v.pf[hf].z) + v.pb[hf].z; f[3] = (f[3] + v.pf[hf].w) + v.pb[hf].w;
+                    }
                     h4v p0, p1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1140,7 +1208,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                 }
             };
             auto xslot = [&](int t) { return &xpl[(((t / TCH) & 1) * TCH + (t % TCH)) * TSTEP]; };
-            float4 xnext[2];
+            XRows xnext;
             chunk_load(0, xnext); chunk_store(0, xnext);
             if (TCH < T) chunk_load(1, xnext);
             __syncthreads();
@@ -1166,11 +1234,15 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
             // residual rows of group f are REQUESTED in iteration f + 1 (fc_request) and the group is finished in iteration f + 2
             // (fc_finish: A rows = (sequence, step) of h1 as in the batched input half, 6 MFMAs, epilogue), when the gate that
             // iteration waits for anyway - layer 1 has finished group f - says its h1 is complete
-            float xres[4] = {0.f, 0.f, 0.f, 0.f};
+            float xres[4] = {0.f, 0.f, 0.f, 0.f}, xpf[PART ? 4 : 1] = {}, xpb[PART ? 4 : 1] = {};
             auto fc_request = [&](int f) {
                 const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xres[e] = zin[base_q + (size_t)(ffirst + (e < nst ? e : nst - 1)) * tstride + unit];
+                for (int e = 0; e < 4; ++e) {
+                    const size_t row = base_q + (size_t)(ffirst + (e < nst ? e : nst - 1)) * tstride;
+                    xres[e] = zin[row + unit];
+                    if (PART) { xpf[e] = part[2 * row + unit]; xpb[e] = part[2 * row + HID + unit]; }
+                }
             };
             auto fc_finish = [&](int f) {
                 const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
@@ -1190,7 +1262,9 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                 lds_arrive(&sync[SY_FC], lane);                       // the group's h1 slots are free again
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (e < nst && nq_raw < N) hout[base_q + (size_t)(ffirst + e) * tstride + unit] = ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + xres[e];
+                    if (e < nst && nq_raw < N)
+                        hout[base_q + (size_t)(ffirst + e) * tstride + unit] =
+                            ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + (PART ? (xres[e] + xpf[e]) + xpb[e] : xres[e]);
             };
             __syncthreads();
             for (int g = 0; g < G; ++g) {
@@ -1417,13 +1491,16 @@ bool time_lstm_fuses_fc()
 
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,
-                      const void* fc16, const float* fcb)
+                      const void* fc16, const float* fcb, const float* part)
 {
     const int N = R * K;
     if (N <= 0 || T <= 0) return;
     dim3 grid((N + 3) / 4), block(512), block16(1024);
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
-        if (time_lstm_fuses_fc() && fc16 && fcb)
+        if (time_lstm_fuses_fc() && fc16 && fcb && part)
+            hipLaunchKernelGGL((time_lstm_h2w_kernel<true, false, true>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
+                               state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr, part);
+        else if (time_lstm_fuses_fc() && fc16 && fcb)
             hipLaunchKernelGGL((time_lstm_h2w_kernel<true, false>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
                                state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr);
         else if (time_kernel_variant() >= 1)

@@ -121,6 +121,25 @@ def test_48_row_geometry_of_the_widest_band_is_at_rounding_level():
         assert rel < 1e-5, (k, rel)
 
 
+@pytest.mark.parametrize("kind", ["b12", "b41"])
+def test_dual_path_flows_agree_at_rounding_level(kind):
+    """The recurrent blocks have three ways through the library, selected per process: the default (the band block's fc formed as two
+    per-direction shares inside the second band layer and added, with the residual, by the time-axis launch's staging wave; the time
+    block's fc inside the 16-wave time kernel), BSRNN_BAND_FC=gemm (the band block's fc + residual as a grouped-GEMM launch, rounds
+    1-2) and BSRNN_TIME_KERNEL=v2 on top of it (round 2's 8-wave time kernel + a GEMM launch for its fc).  Same fp16x2 products, sums
+    taken in a different order for the fc: everything the model returns agrees to 1e-5 of its range; the two GEMM-fc flows that
+    differ only in the time kernel (bit-identical h and state by construction) agree to the same bound."""
+    with tempfile.TemporaryDirectory() as d:
+        _, part = run_child(kind, {}, d, "part")
+        _, gemm = run_child(kind, {"BSRNN_BAND_FC": "gemm"}, d, "gemm")
+        _, v2 = run_child(kind, {"BSRNN_BAND_FC": "gemm", "BSRNN_TIME_KERNEL": "v2"}, d, "v2")
+    for name, a, b in (("parts vs gemm fc", part, gemm), ("16-wave vs 8-wave time kernel", gemm, v2)):
+        for k in a:
+            rel = maxabs(a[k], b[k]) / np.abs(b[k]).max()
+            print("%s, %s: %.2e of the range" % (name, k, rel))
+            assert rel < 1e-5, (name, k, rel)
+
+
 def test_config2_16bit_gemm_mode_full_size():
     """BASELINE config 2: R = 32 x 8 s @ 16 kHz with 16-bit GEMM operands (BSRNN_GEMM=fp16: one MFMA term, fp32 accumulate,
     the LSTMs stay fp16x2) against the fp32-accurate default on the same batch: within 1e-2 of the output range."""

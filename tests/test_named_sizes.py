@@ -153,11 +153,17 @@ def test_hip_chunks_of_256_frames_equal_offline(sd_default):
     from oracle import bsrnn_numpy as onp
     from speechseparation_amd import weights
     m = make_model(sd_default)
-    for R, tol in ((2, 3e-5), (64, 3e-5)):
+    # The same kernels do the same arithmetic per row and per frame whatever the call's shape, so chunked == offline EXACTLY and a
+    # call repeats itself bit for bit.  (R = 64 x 512 frames = 32 768 band sequences is also the regression test of a race that only
+    # showed once a launch's buffers outgrew the Infinity Cache: the band kernels' first step could overwrite x_0 while a late wave
+    # was still reading it - a few sequences off by 1e-5 ... 1e-1, different ones every run.)
+    for R, tol in ((2, 0.0), (64, 0.0)):
         wave = weights.synth_waveform(R, 511 * 1024 + 9, seed=60 + R)        # T = 512 = two chunks of 256
         x = m.stft(torch.from_numpy(wave).cuda())
         assert x.shape[2] == 512
-        y_off = m(x)
+        y_off = m(x).clone()
+        for _ in range(2):
+            assert torch.equal(m(x), y_off), "offline forward is not bit-reproducible run to run (R = %d)" % R
         state = torch.zeros((4, 2, R * 12, 64), device="cuda")
         ys = []
         for a in (0, 256):
@@ -165,7 +171,7 @@ def test_hip_chunks_of_256_frames_equal_offline(sd_default):
             ys.append(y)
         e = maxabs(torch.cat(ys, 2).cpu().numpy(), y_off.cpu().numpy())
         print("R = %d: two chunks of 256 frames vs offline %.3e" % (R, e))
-        assert e < tol
+        assert e <= tol
         if R == 2:
             ref = onp.forward(sd_default, x[:, :, :6].cpu().numpy())
             assert maxabs(y_off[:, :, :6].cpu().numpy(), ref) < TOL
