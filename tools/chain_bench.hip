@@ -139,6 +139,25 @@ int main(int argc, char** argv)
             (tw ? aw : ar) += (double)built[t.x].cost * descs[t.x].RT + 200.0;
             tasks.push_back(t);
         }
+    } else if (getenv("CHAIN_ORDER")) {
+        // explicit dispatch order, e.g. CHAIN_ORDER=9,10:88,8,10,7,6 : band[:number of workgroups]; what is left follows in the default order
+        std::vector<std::vector<int2>> per(K);
+        auto band_of = [&](int di) { return descs[di].z_off / H; };
+        for (const int2& t : wide) per[band_of(t.x)].push_back(t);
+        for (const int2& t : rest) per[band_of(t.x)].push_back(t);
+        std::vector<size_t> cur(K, 0);
+        const char* p = getenv("CHAIN_ORDER");
+        while (*p) {
+            const int b = atoi(p);
+            while (*p && *p != ',' && *p != ':') ++p;
+            size_t n = per[b].size();
+            if (*p == ':') { n = (size_t)atoi(++p); while (*p && *p != ',') ++p; }
+            for (size_t k = 0; k < n && cur[b] < per[b].size(); ++k) tasks.push_back(per[b][cur[b]++]);
+            if (*p) ++p;
+        }
+        for (const int2& t : wide) { const int b = band_of(t.x); if (cur[b] < per[b].size() && per[b][cur[b]].y <= t.y) { tasks.push_back(t); ++cur[b]; } }
+        for (const int2& t : rest) { const int b = band_of(t.x); if (cur[b] < per[b].size() && per[b][cur[b]].y <= t.y) { tasks.push_back(t); ++cur[b]; } }
+        if (tasks.size() != wide.size() + rest.size()) { printf("CHAIN_ORDER: %zu of %zu tasks placed\n", tasks.size(), wide.size() + rest.size()); return 1; }
     } else {
         tasks = wide; tasks.insert(tasks.end(), rest.begin(), rest.end());
     }
