@@ -391,13 +391,78 @@ __global__ __launch_bounds__(256) void layout_kernel(FftTables tb, const float* 
     }
 }
 
+// The same transpose for calls of many frames (T >= 32): a workgroup moves 64 interleaved columns x up to 128 frames.  On the
+// [C][2050][T] side the 64 rows of a tile are ONE contiguous range when the tile spans all T frames (T <= 128: the offline sizes),
+// read / written with 16-byte accesses where T allows; on the frame-major side a wave moves the 64 consecutive columns of one frame
+// (256 bytes) per instruction.  32 KB in and out per workgroup instead of 4 KB: 47-49 -> 3x us per launch at R = 64, T = 126.
+constexpr int LF = 64, LT = 128;
+template <bool TO_FRAME_MAJOR>
+__global__ __launch_bounds__(256) void layout_wide_kernel(FftTables tb, const float* __restrict__ src, float* __restrict__ dst, int T)
+{
+    __shared__ float tile[LF][LT + 1];                         // [column][frame], + 1: conflict-free in both directions
+    const int c = blockIdx.z, f0 = blockIdx.y * LF, t0 = blockIdx.x * LT;
+    const int nf = F2 - f0 < LF ? F2 - f0 : LF, nt = T - t0 < LT ? T - t0 : LT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t cm0 = ((size_t)c * F2 + f0) * T + t0;         // first element of the tile on that side (row stride T)
+    const bool whole = nt == T;                                // the tile's rows are adjacent in memory
+    const float* const cmp = TO_FRAME_MAJOR ? src : dst;       // the [C][2050][T] side
+    const bool vec4 = whole && ((nf * T) & 3) == 0 && ((cm0 & 3) == 0) && ((reinterpret_cast<size_t>(cmp) & 15) == 0);
+    // frame-major side: lane = column of the tile, one frame per wave instruction
+    const int fcol = f0 + lane;
+    const bool col_ok = lane < nf;
+    const int dcol = col_ok ? tb.colmap[fcol >> 1] + (fcol & 1) : 0;
+    if (TO_FRAME_MAJOR) {
+        if (vec4) {
+            const int n4 = nf * T / 4;
+            for (int i = tid; i < n4; i += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(src + cm0 + 4 * (size_t)i);
+                int f = (4 * i) / T, t = 4 * i - f * T;
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { tile[f][t] = e[k]; if (++t == T) { t = 0; ++f; } }
+            }
+        } else {
+            for (int f = wave; f < nf; f += 4)
+                for (int t = lane; t < nt; t += 64) tile[f][t] = src[cm0 + (size_t)f * T + t];
+        }
+        __syncthreads();
+        if (col_ok)
+            for (int t = wave; t < nt; t += 4) dst[((size_t)c * T + t0 + t) * tb.ld + dcol] = tile[lane][t];
+    } else {
+        if (col_ok)
+            for (int t = wave; t < nt; t += 4) tile[lane][t] = src[((size_t)c * T + t0 + t) * tb.ld + dcol];
+        __syncthreads();
+        if (vec4) {
+            const int n4 = nf * T / 4;
+            for (int i = tid; i < n4; i += 256) {
+                int f = (4 * i) / T, t = 4 * i - f * T;
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e[k] = tile[f][t]; if (++t == T) { t = 0; ++f; } }
+                *reinterpret_cast<float4*>(dst + cm0 + 4 * (size_t)i) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        } else {
+            for (int f = wave; f < nf; f += 4)
+                for (int t = lane; t < nt; t += 64) dst[cm0 + (size_t)f * T + t] = tile[f][t];
+        }
+    }
+}
+
 void launch_to_frame_major(const FftTables& tb, const float* x, float* xf, int C, int T, hipStream_t s)
 {
+    if (T >= 32) {
+        hipLaunchKernelGGL(layout_wide_kernel<true>, dim3((T + LT - 1) / LT, (F2 + LF - 1) / LF, C), dim3(256), 0, s, tb, x, xf, T);
+        return;
+    }
     dim3 grid((T + 31) / 32, (F2 + 31) / 32, C);
     hipLaunchKernelGGL(layout_kernel<true>, grid, dim3(256), 0, s, tb, x, xf, T);
 }
 void launch_from_frame_major(const FftTables& tb, const float* yf, float* y, int C, int T, hipStream_t s)
 {
+    if (T >= 32) {
+        hipLaunchKernelGGL(layout_wide_kernel<false>, dim3((T + LT - 1) / LT, (F2 + LF - 1) / LF, C), dim3(256), 0, s, tb, yf, y, T);
+        return;
+    }
     dim3 grid((T + 31) / 32, (F2 + 31) / 32, C);
     hipLaunchKernelGGL(layout_kernel<false>, grid, dim3(256), 0, s, tb, yf, y, T);
 }
