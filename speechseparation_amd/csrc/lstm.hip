@@ -20,6 +20,12 @@
 #ifndef BAND_NLDS
 #define BAND_NLDS 2                 // second-piece weight blocks of the 128-input layer kept in LDS (3: 226 VGPRs, 2: 242, 1: 254)
 #endif
+#ifndef BAND_NLDS64
+#define BAND_NLDS64 0               // measurement: second-piece weight blocks of the 64-input layer kept in LDS (2: <= 168 VGPRs, three workgroups per CU)
+#endif
+#ifndef BAND_OCC64
+#define BAND_OCC64 2                // measurement: waves per SIMD requested for the 64-input layer
+#endif
 #ifndef PART_DBG
 #define PART_DBG 0                  // measurement only (tools/band_parts_check.hip): 1 no fc MFMAs, 2 no fclds array (fragments = garbage), 4 no tail
 #endif
@@ -218,7 +224,7 @@ __device__ __forceinline__ void split_h2(float v, _Float16& p0, _Float16& p1)
 // of the block's fc, its 100 MB of traffic and its 18 us are gone.  The product is formed where h_{t} is read back as the next
 // step's B operand anyway: 6 more MFMAs per wave and step on the fragments already in registers, the fc's A fragments from LDS.
 template <int IN, bool TRACE = false, bool PART = false>
-__global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __restrict__ xin, float* __restrict__ hout,
+__global__ __launch_bounds__(256, (IN == 64 ? BAND_OCC64 : 2)) void band_lstm_h2_kernel(const float* __restrict__ xin, float* __restrict__ hout,
                                                               const uint4* __restrict__ wpk, const float* __restrict__ bias,
                                                               int N, int L, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
                                                               const uint4* __restrict__ wfc = nullptr, const float* __restrict__ bfc = nullptr)
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void band_lstm_h2_kernel(const float* __res
     // blocks whose second weight piece lives in LDS instead of VGPRs (counted from the last k block): the 128-input
     // layer would need 192 weight + 32 accumulator registers; with the two W_hh blocks in LDS it is 160 + 32 and
     // compiles without scratch at 242 VGPRs (measured with spills: 1.9 us of every 3.5 us step in reloads)
-    constexpr int NLDS = IN == 128 ? BAND_NLDS : 0;
+    constexpr int NLDS = IN == 128 ? BAND_NLDS : BAND_NLDS64;
     constexpr int XV = IN / 64;                  // 16-byte units per thread per x tile
     __shared__ __attribute__((aligned(16))) _Float16 xpl[2][2][IN * 16];     // [slot][piece][k / 8][seq][8]
     __shared__ __attribute__((aligned(16))) _Float16 hpl[2][2][HID * 16];

@@ -15,7 +15,7 @@ static int lcg() { g_seed = g_seed * 1664525u + 1013904223u; return (int)((g_see
 #define rand lcg
 #undef RAND_MAX
 #define RAND_MAX 0x7fffff
-namespace bsrnn { bool force_f32() { return false; } }
+namespace bsrnn { bool force_f32() { return false; } int gemm_mode() { return GEMM_FP16X2; } }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 // fills every CU's LDS (and a few registers) with a pattern: a kernel that reads LDS it did not write shows up as a
