@@ -248,8 +248,17 @@ __global__ __launch_bounds__(256, (IN == 64 ? BAND_OCC64 : 2)) void band_lstm_h2
     __shared__ __attribute__((aligned(16))) float bias_lds[4 * HID];         // this direction's b_ih + b_hh, [gate][unit]
     __shared__ __attribute__((aligned(16))) uint4 fclds[PART && !(PART_DBG & 2) ? 4 * 2 * 2 * 64 : 1];   // fc A fragments [wave][k block][piece][lane]
 
-    const int dir = blockIdx.y;
-    const int n0 = blockIdx.x * 16;
+    // Workgroup -> (tile of 16 sequences, direction).  The two directions of a tile read the same x rows: in the 1-D grid of
+    // launch_band_lstm they are 8 workgroup ids apart - the same XCD (id % 8), dispatched together - so the second read of a row
+    // is served by that XCD's L2 instead of a second trip to memory (2-D grids, the measurement tools': direction = blockIdx.y).
+    int dir = blockIdx.y, tile = blockIdx.x;
+    if (gridDim.y == 1) {
+        const int w = blockIdx.x & 15;
+        dir = w >> 3;
+        tile = (blockIdx.x >> 4) * 8 + (w & 7);
+        if (tile * 16 >= N) return;
+    }
+    const int n0 = tile * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
 
@@ -499,6 +508,8 @@ void launch_band_lstm(const float* xin, float* hout, const float* wpk, const voi
     if (N <= 0 || L <= 0) return;
     dim3 grid((N + 15) / 16, 2), block(256);
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
+        static const bool paired = [] { const char* e = getenv("BSRNN_BAND_GRID"); return !(e && !strcmp(e, "2d")); }();   // A/B: 2d = one direction after the other
+        if (paired) grid = dim3((((N + 15) / 16 + 7) / 8) * 16);      // both directions of eight tiles per 16 consecutive workgroups
         if (IN == 128 && fc16) {
             hipLaunchKernelGGL((band_lstm_h2_kernel<128, false, true>), grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, range_flag,
                                (unsigned long long*)nullptr, (const uint4*)fc16, fcb);
@@ -994,6 +1005,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float pinb[2 * 2 * 4 * 4 * 256];   // [layer][group parity][step in group][gate][cell]: bias + input half
     __shared__ __attribute__((aligned(16))) uint4 wflds[FUSE ? 4 * 4 * 64 : 1];
     __shared__ int sync[SY_COUNT];            // the counters (and the abort word) of lds_wait_ge / lds_arrive
+    __shared__ float hb_lds[PART ? 512 : 1];  // PART: the helpers' biases [layer][gate][unit]
 
     const int N = R * K;
     const int n0 = blockIdx.x * 4;
@@ -1017,7 +1029,252 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
     if (tid < SY_COUNT) sync[tid] = 0;
     if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
 
-    if (role < 2) {
+    // The two role families are laid out as "helpers: ...; return;  main waves: ..." and not as if / else: with a join behind both, the
+    // structurizer keeps the values of the path laid out second alive through the first one's loops (a wave runs only one of them, but
+    // the compiler sees entry -> helpers -> join -> main as a path) - a dozen registers the 128-VGPR budget of 16 waves per CU does not have.
+    auto finish = [&]() {
+        if (lds_peek(&sync[SY_ABORT]) && range_flag) *range_flag = 3;
+        if (TRACE && lane == 0 && blockIdx.x < 4) {
+            unsigned long long* d = dbg + (blockIdx.x * 16 + wave) * 4;
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = tp[k];
+        }
+    };
+    if (role >= 2) {
+        // ------------------------------------------------------------------ helper waves: input halves, x staging, fc
+        h8v w[2][4][2];                           // W_ih (fc_in folded for layer 0): [k block][gate][piece]
+        {
+            const uint4* wp = wpk + ((size_t)(layer * 4 + w4) * 4 * 4 * 2) * 64 + lane;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[((b * 4 + gte) * 2 + pc) * 64]);
+        }
+        float bs[4];
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) {
+            bs[gte] = bias[layer * 256 + gte * 64 + unit];
+            if (PART) hb_lds[layer * 256 + gte * 64 + unit] = bs[gte];      // (read back after the workgroup's first barrier)
+        }
+        float bf = 0.f;
+        if (FUSE && layer) {                      // the fc matrix as B fragments [k block][piece] (column = output feature `unit`): used once per
+            const uint4* wp = wfc + ((size_t)w4 * 2 * 2) * 64 + lane;       // group, so it lives in LDS; a wave reads back what it wrote itself
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wflds[(w4 * 4 + i) * 64 + lane] = wp[i * 64];
+            bf = bfc[unit];
+        }
+        // input half of the four steps of `group` (A rows = (sequence, step), `src` = slot of the group's first step): per gate
+        // 6 MFMAs, then bias + result to the LDS buffer the main wave of this cell reads, [step][gate][cell]
+        auto input_half = [&](const _Float16* src, int group) {
+            if (TIME_ABL & 8) return;
+            const _Float16* mine = src + bstep * TSTEP;
+            h8v a0[2], a1[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                a0[b] = *reinterpret_cast<const h8v*>(&mine[b * 128 + afrag]);
+                a1[b] = *reinterpret_cast<const h8v*>(&mine[4 * HID + b * 128 + afrag]);
+            }
+            float* dst = pinb + layer * 8192 + (group & 1) * 4096 + cellid;
+            float bsg[4];                         // PART: the biases come from LDS per group instead of living in four registers across the
+#pragma unroll                                    // loop - the kernel has none to spare (no scratch: see H0)
+            for (int gte = 0; gte < 4; ++gte) bsg[gte] = PART ? hb_lds[layer * 256 + gte * 64 + unit] : bs[gte];
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) {
+                v4f ghi = zero4, glo = zero4;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (TIME_ABL & 2) { ghi[0] += (float)a0[b][0] * (float)w[b][gte][0][0]; glo[1] += (float)a1[b][1] * (float)w[b][gte][1][1]; continue; }
+                    ghi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][0], ghi, 0, 0, 0);
+                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][1], glo, 0, 0, 0);
+                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[b], w[b][gte][0], glo, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e * 1024 + gte * 256] = bsg[gte] + (ghi[e] + glo[e] * (1.f / 2048.f));
+            }
+        };
+        if (!layer) {
+            // ---------------- H0: x staging (its 256 threads: 8 steps x 4 sequences x 16 float4 = 512 float4, two per thread) and
+            // the input half of layer 0.  Chunk c (steps 8 c ...) lives in slot c & 1; it is requested a whole chunk ahead,
+            // stored once every H0 wave has published the groups that read the slot's previous content, and read once every
+            // H0 wave has stored its share.
+            const int xs_t = cellid >> 6, xs_i = (cellid >> 4) & 3, xs_c4 = cellid & 15;      // thread -> (step 0-3 [+4], sequence, float4)
+            size_t xs_base;
+            {
+                int ni = n0 + xs_i; ni = ni < N ? ni : N - 1;
+                xs_base = ((size_t)(ni / K) * T * K + (ni % K)) * HID + 4 * xs_c4;
+            }
+            float amax = 0.f;                    // range guard
+            struct XRows { float4 z[2]; };
+            auto chunk_load = [&](int chunk, XRows& v) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    int t = chunk * TCH + xs_t + 4 * hf;
+                    t = t < T ? t : T - 1;
+                    v.z[hf] = *reinterpret_cast<const float4*>(zin + xs_base + (size_t)t * tstride);
+                }
+            };
+            auto chunk_store = [&](int chunk, const XRows& v) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float f[4] = {v.z[hf].x, v.z[hf].y, v.z[hf].z, v.z[hf].w};
+                    h4v p0, p1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
+                        _Float16 a, b2;
+                        split_h2(f[e], a, b2);
+                        p0[e] = a; p1[e] = b2;
+                    }
+                    _Float16* dst = &xpl[((chunk & 1) * TCH + xs_t + 4 * hf) * TSTEP + ((xs_c4 >> 1) * 4 + xs_i) * 8 + (xs_c4 & 1) * 4];
+                    *reinterpret_cast<h4v*>(dst) = p0;
+                    *reinterpret_cast<h4v*>(dst + 4 * HID) = p1;
+                }
+            };
+            auto xslot = [&](int t) { return &xpl[(((t / TCH) & 1) * TCH + (t % TCH)) * TSTEP]; };
+            if (PART) {
+                // PART stages group by group instead of chunk by chunk: three rows per (sequence, step) - residual and the two fc shares -
+                // would be 24 registers held across the input half (the kernel then spills: 1024 threads leave 128 VGPRs per wave);
+                // one group's rows are 12.  A group's four steps are requested one group ahead, stored (summed) at the top of the
+                // next iteration once every wave has published the group that used the same slots (four groups = 16 steps earlier).
+                struct GRows { float4 z, pf, pb; };
+                auto rows_of = [&](int g) { int t = 4 * g + xs_t; t = t < T ? t : T - 1; return xs_base + (size_t)t * tstride; };
+                auto load_z = [&](int g, GRows& v) { v.z = *reinterpret_cast<const float4*>(zin + rows_of(g)); };
+                auto load_shares = [&](int g, GRows& v) {
+                    const float* pp = part + 2 * (rows_of(g) - 4 * xs_c4) + 4 * xs_c4;
+                    v.pf = *reinterpret_cast<const float4*>(pp);
+                    v.pb = *reinterpret_cast<const float4*>(pp + HID);
+                };
+                auto group_store = [&](int g, const GRows& v) {
+                    const float f[4] = {(v.z.x + v.pf.x) + v.pb.x, (v.z.y + v.pf.y) + v.pb.y, (v.z.z + v.pf.z) + v.pb.z, (v.z.w + v.pf.w) + v.pb.w};
+                    h4v p0, p1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
+                        _Float16 a, b2;
+                        split_h2(f[e], a, b2);
+                        p0[e] = a; p1[e] = b2;
+                    }
+                    _Float16* dst = xslot(4 * g + xs_t) + ((xs_c4 >> 1) * 4 + xs_i) * 8 + (xs_c4 & 1) * 4;
+                    *reinterpret_cast<h4v*>(dst) = p0;
+                    *reinterpret_cast<h4v*>(dst + 4 * HID) = p1;
+                    // ... and to the OUTPUT buffer, where the fc wave (H1) picks it up as its residual two groups later and then
+                    // overwrites it with the block's result: one read of the three rows instead of two.  Same workgroup, same CU:
+                    // the store is complete (vmcnt(0) in front of this wave's PIN0 arrival below) long before the chain H0 -> M0 ->
+                    // H1 of LDS counters lets H1 ask for it, and nobody has read that line before (no stale copy in the L1).
+                    if (n0 + xs_i < N && 4 * g + xs_t < T) *reinterpret_cast<float4*>(hout + rows_of(g)) = make_float4(f[0], f[1], f[2], f[3]);
+                };
+                // Only the residual row (4 registers) is in flight across an input half; the two share rows of the next group are
+                // requested BEHIND it and land during the waits at the top of the next iteration: the kernel must stay inside 128
+                // VGPRs without scratch (with spills - the weight fragments, reloaded in the loops - a call beside a second
+                // process's first kernels came out a few ulp different once in ~50: tools/busy_start_stress.py).
+                GRows xr;
+                load_z(0, xr); load_shares(0, xr); group_store(0, xr);
+                if (G > 1) { load_z(1, xr); load_shares(1, xr); }
+                __syncthreads();
+                for (int g = 0; g < G; ++g) {
+                    if (g) {
+                        if (g >= 4) lds_wait_ge(sync, SY_PIN0, 4 * (g - 3));   // group g - 4 (the same slots) is published by every wave
+                        group_store(g, xr);
+                        lds_arrive(&sync[SY_X], lane);
+                        if (g + 1 < G) load_z(g + 1, xr);
+                        lds_wait_ge(sync, SY_X, 4 * g);                    // every wave has stored its share of group g
+                    }
+                    if (g >= 2) lds_wait_ge(sync, SY_DONE0, 16 * (g - 1));   // layer 0 has finished group g - 2 (same buffer)
+                    stamp(0);
+                    input_half(xslot(4 * g), g);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's row stores of the group are in L2
+                    lds_arrive(&sync[SY_PIN0], lane);
+                    if (g && g + 1 < G) load_shares(g + 1, xr);
+                    stamp(2);
+                }
+            } else {
+            XRows xnext;
+            chunk_load(0, xnext); chunk_store(0, xnext);
+            if (TCH < T) chunk_load(1, xnext);
+            __syncthreads();
+            for (int g = 0; g < G; ++g) {
+                const int ch = g >> 1;
+                if (g && !(g & 1)) {                                  // first group of chunk ch >= 1
+                    lds_wait_ge(sync, SY_PIN0, 4 * (2 * ch - 2));    // the groups that read chunk ch - 2 (same slot) are published by every wave
+                    chunk_store(ch, xnext);
+                    lds_arrive(&sync[SY_X], lane);
+                    if ((ch + 1) * TCH < T) chunk_load(ch + 1, xnext);
+                    lds_wait_ge(sync, SY_X, 4 * ch);                 // every wave has stored its share of chunk ch
+                }
+                if (g >= 2) lds_wait_ge(sync, SY_DONE0, 16 * (g - 1));   // layer 0 has finished group g - 2 (same buffer)
+                stamp(0);
+                input_half(xslot(4 * g), g);
+                lds_arrive(&sync[SY_PIN0], lane);
+                stamp(2);
+            }
+            }
+            if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
+        } else {
+            // ---------------- H1: input half of layer 1 (A = h0 of the group, complete once layer 0 has finished its last step)
+            // FUSE: fc + residual of a group of layer 1 in two stages, so that H1 never waits for anything but its own gates: the
+            // residual rows of group f are REQUESTED in iteration f + 1 (fc_request) and the group is finished in iteration f + 2
+            // (fc_finish: A rows = (sequence, step) of h1 as in the batched input half, 6 MFMAs, epilogue), when the gate that
+            // iteration waits for anyway - layer 1 has finished group f - says its h1 is complete
+            float xres[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* const res_src = PART ? hout : zin;     // PART: the staging wave left the summed row (residual + fc shares) in the output buffer
+            auto fc_request = [&](int f) {
+                const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const size_t row = base_q + (size_t)(ffirst + (e < nst ? e : nst - 1)) * tstride;
+                    xres[e] = res_src[row + unit];
+                }
+            };
+            auto fc_finish = [&](int f) {
+                const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
+                const _Float16* mine = &h1pl[((ffirst & (H1RING - 1)) + bstep) * TSTEP];
+                v4f fhi = zero4, flo = zero4;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const h8v f0 = *reinterpret_cast<const h8v*>(&mine[b * 128 + afrag]);
+                    const h8v f1 = *reinterpret_cast<const h8v*>(&mine[4 * HID + b * 128 + afrag]);
+                    const h8v wf0 = __builtin_bit_cast(h8v, wflds[(w4 * 4 + b * 2 + 0) * 64 + lane]);
+                    const h8v wf1 = __builtin_bit_cast(h8v, wflds[(w4 * 4 + b * 2 + 1) * 64 + lane]);
+                    fhi = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf0, fhi, 0, 0, 0);
+                    flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf1, flo, 0, 0, 0);
+                    flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, wf0, flo, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);                // one block's fragments at a time (registers)
+                }
+                lds_arrive(&sync[SY_FC], lane);                       // the group's h1 slots are free again
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nst && nq_raw < N)
+                        hout[base_q + (size_t)(ffirst + e) * tstride + unit] =
+                            ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + xres[e];
+            };
+            __syncthreads();
+            for (int g = 0; g < G; ++g) {
+                const int last = 4 * g + 4 < T ? 4 * g + 4 : T;
+                lds_wait_ge(sync, SY_DONE0, 4 * last);               // h0 of the group complete
+                if (g >= 2) lds_wait_ge(sync, SY_DONE1, 16 * (g - 1));   // layer 1 has finished group g - 2 (same buffer; its h1 is complete)
+                stamp(0);
+                input_half(&h0pl[((4 * g) & (H0RING - 1)) * TSTEP], g);
+                lds_arrive(&sync[SY_PIN1], lane);
+                stamp(2);
+                if (FUSE) {
+                    if (g >= 2) fc_finish(g - 2);
+                    if (g >= 1) fc_request(g - 1);
+                }
+                stamp(1);
+            }
+            if (FUSE) {                           // the last two groups
+                if (G >= 2) { lds_wait_ge(sync, SY_DONE1, 16 * (G - 1)); fc_finish(G - 2); }
+                fc_request(G - 1);
+                lds_wait_ge(sync, SY_DONE1, 4 * T);
+                fc_finish(G - 1);
+            }
+        }
+        finish();
+        return;
+    }
+    {
         // ------------------------------------------------------------------ main waves: the serial chain
         h8v w[2][4][2];                           // W_hh: [k block][gate][piece]
         {
@@ -1118,189 +1375,8 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
             state_out[((size_t)layer * N + nq) * HID + unit] = hsel;           // h_{T-1}
             state_out[((size_t)(2 + layer) * N + nq) * HID + unit] = csel;     // c_{T-1}
         }
-    } else {
-        // ------------------------------------------------------------------ helper waves: input halves, x staging, fc
-        h8v w[2][4][2];                           // W_ih (fc_in folded for layer 0): [k block][gate][piece]
-        {
-            const uint4* wp = wpk + ((size_t)(layer * 4 + w4) * 4 * 4 * 2) * 64 + lane;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int gte = 0; gte < 4; ++gte)
-#pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[((b * 4 + gte) * 2 + pc) * 64]);
-        }
-        float bs[4];
-#pragma unroll
-        for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[layer * 256 + gte * 64 + unit];
-        float bf = 0.f;
-        if (FUSE && layer) {                      // the fc matrix as B fragments [k block][piece] (column = output feature `unit`): used once per
-            const uint4* wp = wfc + ((size_t)w4 * 2 * 2) * 64 + lane;       // group, so it lives in LDS; a wave reads back what it wrote itself
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wflds[(w4 * 4 + i) * 64 + lane] = wp[i * 64];
-            bf = bfc[unit];
-        }
-        // input half of the four steps of `group` (A rows = (sequence, step), `src` = slot of the group's first step): per gate
-        // 6 MFMAs, then bias + result to the LDS buffer the main wave of this cell reads, [step][gate][cell]
-        auto input_half = [&](const _Float16* src, int group) {
-            if (TIME_ABL & 8) return;
-            const _Float16* mine = src + bstep * TSTEP;
-            h8v a0[2], a1[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                a0[b] = *reinterpret_cast<const h8v*>(&mine[b * 128 + afrag]);
-                a1[b] = *reinterpret_cast<const h8v*>(&mine[4 * HID + b * 128 + afrag]);
-            }
-            float* dst = pinb + layer * 8192 + (group & 1) * 4096 + cellid;
-#pragma unroll
-            for (int gte = 0; gte < 4; ++gte) {
-                v4f ghi = zero4, glo = zero4;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if (TIME_ABL & 2) { ghi[0] += (float)a0[b][0] * (float)w[b][gte][0][0]; glo[1] += (float)a1[b][1] * (float)w[b][gte][1][1]; continue; }
-                    ghi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][0], ghi, 0, 0, 0);
-                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][1], glo, 0, 0, 0);
-                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[b], w[b][gte][0], glo, 0, 0, 0);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dst[e * 1024 + gte * 256] = bs[gte] + (ghi[e] + glo[e] * (1.f / 2048.f));
-            }
-        };
-        if (!layer) {
-            // ---------------- H0: x staging (its 256 threads: 8 steps x 4 sequences x 16 float4 = 512 float4, two per thread) and
-            // the input half of layer 0.  Chunk c (steps 8 c ...) lives in slot c & 1; it is requested a whole chunk ahead,
-            // stored once every H0 wave has published the groups that read the slot's previous content, and read once every
-            // H0 wave has stored its share.
-            const int xs_t = cellid >> 6, xs_i = (cellid >> 4) & 3, xs_c4 = cellid & 15;      // thread -> (step 0-3 [+4], sequence, float4)
-            size_t xs_base;
-            {
-                int ni = n0 + xs_i; ni = ni < N ? ni : N - 1;
-                xs_base = ((size_t)(ni / K) * T * K + (ni % K)) * HID + 4 * xs_c4;
-            }
-            float amax = 0.f;                    // range guard
-            struct XRows { float4 z[2], pf[PART ? 2 : 1], pb[PART ? 2 : 1]; };
-            auto chunk_load = [&](int chunk, XRows& v) {
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    int t = chunk * TCH + xs_t + 4 * hf;
-                    t = t < T ? t : T - 1;
-                    v.z[hf] = *reinterpret_cast<const float4*>(zin + xs_base + (size_t)t * tstride);
-                    if (PART) {
-                        const float* pp = part + 2 * (xs_base - 4 * xs_c4 + (size_t)t * tstride) + 4 * xs_c4;
-                        v.pf[hf] = *reinterpret_cast<const float4*>(pp);
-                        v.pb[hf] = *reinterpret_cast<const float4*>(pp + HID);
-                    }
-                }
-            };
-            auto chunk_store = [&](int chunk, const XRows& v) {
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    float f[4] = {v.z[hf].x, v.z[hf].y, v.z[hf].z, v.z[hf].w};
-                    if (PART) {
-                        f[0] = (f[0] + v.pf[hf].x) + v.pb[hf].x; f[1] = (f[1] + v.pf[hf].y) + v.pb[hf].y;
-                        f[2] = (f[2] + v.pf[hf].z) + v.pb[hf].z; f[3] = (f[3] + v.pf[hf].w) + v.pb[hf].w;
-                    }
-                    h4v p0, p1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
-                        _Float16 a, b2;
-                        split_h2(f[e], a, b2);
-                        p0[e] = a; p1[e] = b2;
-                    }
-                    _Float16* dst = &xpl[((chunk & 1) * TCH + xs_t + 4 * hf) * TSTEP + ((xs_c4 >> 1) * 4 + xs_i) * 8 + (xs_c4 & 1) * 4];
-                    *reinterpret_cast<h4v*>(dst) = p0;
-                    *reinterpret_cast<h4v*>(dst + 4 * HID) = p1;
-                }
-            };
-            auto xslot = [&](int t) { return &xpl[(((t / TCH) & 1) * TCH + (t % TCH)) * TSTEP]; };
-            XRows xnext;
-            chunk_load(0, xnext); chunk_store(0, xnext);
-            if (TCH < T) chunk_load(1, xnext);
-            __syncthreads();
-            for (int g = 0; g < G; ++g) {
-                const int ch = g >> 1;
-                if (g && !(g & 1)) {                                  // first group of chunk ch >= 1
-                    lds_wait_ge(sync, SY_PIN0, 4 * (2 * ch - 2));    // the groups that read chunk ch - 2 (same slot) are published by every wave
-                    chunk_store(ch, xnext);
-                    lds_arrive(&sync[SY_X], lane);
-                    if ((ch + 1) * TCH < T) chunk_load(ch + 1, xnext);
-                    lds_wait_ge(sync, SY_X, 4 * ch);                 // every wave has stored its share of chunk ch
-                }
-                if (g >= 2) lds_wait_ge(sync, SY_DONE0, 16 * (g - 1));   // layer 0 has finished group g - 2 (same buffer)
-                stamp(0);
-                input_half(xslot(4 * g), g);
-                lds_arrive(&sync[SY_PIN0], lane);
-                stamp(2);
-            }
-            if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
-        } else {
-            // ---------------- H1: input half of layer 1 (A = h0 of the group, complete once layer 0 has finished its last step)
-            // FUSE: fc + residual of a group of layer 1 in two stages, so that H1 never waits for anything but its own gates: the
-            // residual rows of group f are REQUESTED in iteration f + 1 (fc_request) and the group is finished in iteration f + 2
-            // (fc_finish: A rows = (sequence, step) of h1 as in the batched input half, 6 MFMAs, epilogue), when the gate that
-            // iteration waits for anyway - layer 1 has finished group f - says its h1 is complete
-            float xres[4] = {0.f, 0.f, 0.f, 0.f}, xpf[PART ? 4 : 1] = {}, xpb[PART ? 4 : 1] = {};
-            auto fc_request = [&](int f) {
-                const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const size_t row = base_q + (size_t)(ffirst + (e < nst ? e : nst - 1)) * tstride;
-                    xres[e] = zin[row + unit];
-                    if (PART) { xpf[e] = part[2 * row + unit]; xpb[e] = part[2 * row + HID + unit]; }
-                }
-            };
-            auto fc_finish = [&](int f) {
-                const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
-                const _Float16* mine = &h1pl[((ffirst & (H1RING - 1)) + bstep) * TSTEP];
-                v4f fhi = zero4, flo = zero4;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const h8v f0 = *reinterpret_cast<const h8v*>(&mine[b * 128 + afrag]);
-                    const h8v f1 = *reinterpret_cast<const h8v*>(&mine[4 * HID + b * 128 + afrag]);
-                    const h8v wf0 = __builtin_bit_cast(h8v, wflds[(w4 * 4 + b * 2 + 0) * 64 + lane]);
-                    const h8v wf1 = __builtin_bit_cast(h8v, wflds[(w4 * 4 + b * 2 + 1) * 64 + lane]);
-                    fhi = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf0, fhi, 0, 0, 0);
-                    flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf1, flo, 0, 0, 0);
-                    flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, wf0, flo, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);                // one block's fragments at a time (registers)
-                }
-                lds_arrive(&sync[SY_FC], lane);                       // the group's h1 slots are free again
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < nst && nq_raw < N)
-                        hout[base_q + (size_t)(ffirst + e) * tstride + unit] =
-                            ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + (PART ? (xres[e] + xpf[e]) + xpb[e] : xres[e]);
-            };
-            __syncthreads();
-            for (int g = 0; g < G; ++g) {
-                const int last = 4 * g + 4 < T ? 4 * g + 4 : T;
-                lds_wait_ge(sync, SY_DONE0, 4 * last);               // h0 of the group complete
-                if (g >= 2) lds_wait_ge(sync, SY_DONE1, 16 * (g - 1));   // layer 1 has finished group g - 2 (same buffer; its h1 is complete)
-                stamp(0);
-                input_half(&h0pl[((4 * g) & (H0RING - 1)) * TSTEP], g);
-                lds_arrive(&sync[SY_PIN1], lane);
-                stamp(2);
-                if (FUSE) {
-                    if (g >= 2) fc_finish(g - 2);
-                    if (g >= 1) fc_request(g - 1);
-                }
-                stamp(1);
-            }
-            if (FUSE) {                           // the last two groups
-                if (G >= 2) { lds_wait_ge(sync, SY_DONE1, 16 * (G - 1)); fc_finish(G - 2); }
-                fc_request(G - 1);
-                lds_wait_ge(sync, SY_DONE1, 4 * T);
-                fc_finish(G - 1);
-            }
-        }
     }
-    if (lds_peek(&sync[SY_ABORT]) && range_flag) *range_flag = 3;
-    if (TRACE && lane == 0 && blockIdx.x < 4) {
-        unsigned long long* d = dbg + (blockIdx.x * 16 + wave) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = tp[k];
-    }
+    finish();
 }
 
 // =====================================================================================
@@ -1495,12 +1571,34 @@ bool time_lstm_fuses_fc()
     return lstm_mode() == LSTM_FP16X2 && !force_f32() && gemm_mode() != GEMM_F32 && time_kernel_variant() == 2;
 }
 
+// measurement (BSRNN_BAND_FC=part_add): out = (z + part[.., 0, :]) + part[.., 1, :] as a launch of its own, so that the time kernel
+// runs without PART on the same numbers - separates the two halves of the parts flow when something depends on which one runs
+__global__ void parts_add_kernel(const float* __restrict__ z, const float* __restrict__ part, float* __restrict__ out, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const size_t row = i / 16, c4 = i % 16;
+    const float4 a = reinterpret_cast<const float4*>(z)[i];
+    const float4 f = reinterpret_cast<const float4*>(part)[row * 32 + c4], b = reinterpret_cast<const float4*>(part)[row * 32 + 16 + c4];
+    reinterpret_cast<float4*>(out)[i] = make_float4((a.x + f.x) + b.x, (a.y + f.y) + b.y, (a.z + f.z) + b.z, (a.w + f.w) + b.w);
+}
+static bool parts_add_mode()
+{
+    static const bool on = [] { const char* e = getenv("BSRNN_BAND_FC"); return e && !strcmp(e, "part_add"); }();
+    return on;
+}
+
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,
                       const void* fc16, const float* fcb, const float* part)
 {
     const int N = R * K;
     if (N <= 0 || T <= 0) return;
+    if (part && parts_add_mode() && time_lstm_fuses_fc() && fc16 && fcb) {
+        const size_t n4 = (size_t)R * T * K * 16;          // in place: zin is the block's input from here on (its old content is dead)
+        hipLaunchKernelGGL(parts_add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, zin, part, const_cast<float*>(zin), n4);
+        part = nullptr;                                    // zin now holds the block's input; the plain fused kernel follows
+    }
     dim3 grid((N + 3) / 4), block(512), block16(1024);
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
         if (time_lstm_fuses_fc() && fc16 && fcb && part)

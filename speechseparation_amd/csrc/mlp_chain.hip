@@ -47,6 +47,9 @@ typedef v4f __attribute__((address_space(1)))* g4;
 typedef const h8 __attribute__((address_space(1)))* gch8;
 typedef const char __attribute__((address_space(1)))* gcc;
 
+#ifndef CHAIN_NO_RAG_CODE
+#define CHAIN_NO_RAG_CODE 0     // measurement only: compile the ragged-tile k-split out (register pressure probe)
+#endif
 #ifndef CHAIN_PD
 #define CHAIN_PD 8                 // k-steps of weight fragments in flight per wave (register sets of 2 fragments)
 #endif
@@ -91,7 +94,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
     // GR = 8: every wave is a group of its own (one row tile, all feature tiles of the band, layers up to 128 wide): its
     // activation image is private, so the layer barriers are not needed (a wave's LDS accesses are performed in order)
     constexpr bool SOLO = GR == 8;
-    constexpr bool RAG = RT == 2 && GR == 1;      // the geometry that knows how to split a ragged last tile over the k-steps (host: ChainLayer::rag)
+    constexpr bool RAG = RT == 2 && GR == 1 && !CHAIN_NO_RAG_CODE;      // the geometry that knows how to split a ragged last tile over the k-steps (host: ChainLayer::rag)
     auto group_barrier = [&]() { if (!SOLO) __syncthreads(); };
     float* const sbias = reinterpret_cast<float*>(smem_all + CHAIN_LDS_EX);
     const int tid = threadIdx.x, lane = tid & 63;
