@@ -745,6 +745,16 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
     }
     // geometry of the workgroup (wave-uniform): 48 rows on 16 x 16 tiles, or rows = 32 RT GR on 32 x 32 tiles
     const int RT = dp->RT, GR = 8 / dp->NW;
+#ifdef CHAIN_ONLY_BODY            // measurement only: compile ONE geometry (register / scratch use per body: tools/kernel_resources.py)
+    if (CHAIN_ONLY_BODY == 0) chain_body48<CHAIN, TERMS>(g, dp, row0, smem);
+    else if (CHAIN_ONLY_BODY == 1) chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem);
+    else if (CHAIN_ONLY_BODY == 2) chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem);
+    else if (CHAIN_ONLY_BODY == 3) chain_body<CHAIN, TERMS, 2, 1>(g, dp, row0, smem);
+    else if (CHAIN_ONLY_BODY == 4) chain_body<CHAIN, TERMS, 2, 2>(g, dp, row0, smem);
+    else chain_body<CHAIN, TERMS, 1, 4>(g, dp, row0, smem);
+    (void)RT; (void)GR;
+    return;
+#endif
     if (RT == 3) chain_body48<CHAIN, TERMS>(g, dp, row0, smem);
     else if (GR == 8) chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem);
     else if (RT == 1 && GR == 1) chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem);
