@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256, BAND_OCC) void band_lstm_kernel(const float* _
     constexpr int XV = IN / 64;                  // float4 per thread per x tile
     __shared__ __attribute__((aligned(16))) float xbuf[2][16 * SX];
     __shared__ __attribute__((aligned(16))) float hbuf[2][16 * SH];
+    __shared__ float bias_s[4 * HID];            // this direction's b_ih + b_hh (from LDS every step: the 128-input layer has no registers to spare)
 
     const int dir = blockIdx.y;
     const int n0 = blockIdx.x * 16;
@@ -102,9 +103,7 @@ __global__ __launch_bounds__(256, BAND_OCC) void band_lstm_kernel(const float* _
 #pragma unroll
             for (int gte = 0; gte < 4; ++gte) w[s][gte] = wp[(s * 4 + gte) * 64];
     }
-    float bs[4];
-#pragma unroll
-    for (int gte = 0; gte < 4; ++gte) bs[gte] = bias[dir * 256 + gte * 64 + 16 * wave + l15];
+    bias_s[tid] = bias[dir * 256 + tid];
 
     float c[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -113,23 +112,23 @@ __global__ __launch_bounds__(256, BAND_OCC) void band_lstm_kernel(const float* _
     const int xr_c4[2] = {(tid * XV) % (IN / 4), (tid * XV + 1) % (IN / 4)};
     const int o_row = tid >> 4, o_c4 = tid & 15;
 
-    auto xload = [&](int t, float4* dst) {
+    auto xload = [&](int t, v4f* dst) {      // (native vectors: arrays of HIP's float4 structs stayed in scratch)
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             int row = n0 + xr_row[i];
             row = row < N ? row : N - 1;
-            dst[i] = *reinterpret_cast<const float4*>(xin + ((size_t)row * L + t) * IN + 4 * xr_c4[i]);
+            dst[i] = *reinterpret_cast<const v4f*>(xin + ((size_t)row * L + t) * IN + 4 * xr_c4[i]);
         }
     };
-    auto xstore = [&](int buf, const float4* src) {
+    auto xstore = [&](int buf, const v4f* src) {
 #pragma unroll
         for (int i = 0; i < XV; ++i)
-            *reinterpret_cast<float4*>(&xbuf[buf][xr_row[i] * SX + 4 * xr_c4[i]]) = src[i];
+            *reinterpret_cast<v4f*>(&xbuf[buf][xr_row[i] * SX + 4 * xr_c4[i]]) = src[i];
     };
 
     {   // prologue: h_{-1} = 0, x of the first step
         *reinterpret_cast<float4*>(&hbuf[0][o_row * SH + 4 * o_c4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 x0[XV];
+        v4f x0[XV];
         xload(dir ? L - 1 : 0, x0);
         xstore(0, x0);
     }
@@ -138,13 +137,13 @@ __global__ __launch_bounds__(256, BAND_OCC) void band_lstm_kernel(const float* _
     for (int step = 0; step < L; ++step) {
         const int t = dir ? L - 1 - step : step;
         const int cur = step & 1, nxt = cur ^ 1;
-        float4 xn[XV];
+        v4f xn[XV];
         const bool more = step + 1 < L;
         if (more) xload(dir ? t - 1 : t + 1, xn);
 
         v4f acc[4];
 #pragma unroll
-        for (int gte = 0; gte < 4; ++gte) acc[gte] = (v4f){bs[gte], bs[gte], bs[gte], bs[gte]};
+        for (int gte = 0; gte < 4; ++gte) { const float bsv = bias_s[gte * 64 + 16 * wave + l15]; acc[gte] = (v4f){bsv, bsv, bsv, bsv}; }
 
         const float* xa = &xbuf[cur][l15 * SX + 4 * q];
         const float* ha = &hbuf[cur][l15 * SH + 4 * q];

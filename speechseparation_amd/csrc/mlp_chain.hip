@@ -210,6 +210,12 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
     // registers of the two kinds of epilogue (held tiles / prefetched residual and multiplier rows) never coexist
     auto layer = [&](auto last_tag, const int l) {
         constexpr bool last = decltype(last_tag)::value;
+        // the rows of this workgroup again, behind an opaque asm: the global addresses of the epilogue below are then formed
+        // here, per layer - as loop invariants the compiler computed all of them (14 64-bit pointers) once, in front of the
+        // layer loop, and kept them in scratch (the only scratch use of the kernel, reloaded every layer)
+        int rowl[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) { rowl[r] = row[r]; asm volatile("" : "+v"(rowl[r])); }
         int K16, cnt; gcc wp;
         layer_stream(l, K16, cnt, wp);
         const int boff = dp->L[l].bias_off;
@@ -284,8 +290,8 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                     for (int q = 0; q < 4; ++q) {
                         int n0 = 32 * t + 8 * q + 4 * h;
                         n0 = n0 < dp->a8 ? n0 : 0;
-                        rv[r][q] = *(gc4)((gcf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0);
-                        mv[r][q] = *(gc4)((gcf)g.Xmul + (size_t)row[r] * g.ldm + dp->p_off + n0);
+                        rv[r][q] = *(gc4)((gcf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0);
+                        mv[r][q] = *(gc4)((gcf)g.Xmul + (size_t)rowl[r] * g.ldm + dp->p_off + n0);
                     }
             }
             v16f hi[RT], lo[RT];
@@ -385,16 +391,16 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                         split4(v, p0, p1);
                         held[last ? 0 : c][r][q][0] = p0;
                         held[last ? 0 : c][r][q][NPL - 1] = NPL == 2 ? p1 : p0;
-                        if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0) = v;
+                        if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0) = v;
                     } else if (CHAIN == CHAIN_SPLIT) {
-                        if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)row[r] * g.ldz + dp->z_off + n0) = v;
+                        if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)rowl[r] * g.ldz + dp->z_off + n0) = v;
                     } else {
                         if (row_ok[r] && n0 < dp->a8) {
-                            const v4f rr = PRE_RM ? rv[PRE_RM ? r : 0][q] : *(gc4)((gcf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0);
-                            const v4f mm = PRE_RM ? mv[PRE_RM ? r : 0][q] : *(gc4)((gcf)g.Xmul + (size_t)row[r] * g.ldm + dp->p_off + n0);
+                            const v4f rr = PRE_RM ? rv[PRE_RM ? r : 0][q] : *(gc4)((gcf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0);
+                            const v4f mm = PRE_RM ? mv[PRE_RM ? r : 0][q] : *(gc4)((gcf)g.Xmul + (size_t)rowl[r] * g.ldm + dp->p_off + n0);
                             v += rr;                                                 // mask = residual + post(...)   bsrnn.py:425
-                            if (g.tap) *(g4)((gf)g.tap + (size_t)row[r] * g.ldt + dp->p_off + n0) = v;
-                            *(g4)((gf)g.Y + (size_t)row[r] * g.ldy + dp->p_off + n0) = v * mm;   // x * mask      bsrnn.py:441
+                            if (g.tap) *(g4)((gf)g.tap + (size_t)rowl[r] * g.ldt + dp->p_off + n0) = v;
+                            *(g4)((gf)g.Y + (size_t)rowl[r] * g.ldy + dp->p_off + n0) = v * mm;   // x * mask      bsrnn.py:441
                         }
                     }
                 }
@@ -425,14 +431,14 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                     *reinterpret_cast<h4*>(d) = p0;                       // k-unit 4 t: features n0 .. n0 + 7
                     *reinterpret_cast<h4*>(d + 512) = z4;                 // k-unit 4 t + 1: padding
                     if (NPL == 2) { *reinterpret_cast<h4*>(d + plane) = p1; *reinterpret_cast<h4*>(d + plane + 512) = z4; }
-                    if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0) = v;
+                    if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0) = v;
                 } else if (CHAIN == CHAIN_SPLIT) {
-                    if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)row[r] * g.ldz + dp->z_off + n0) = v;
+                    if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)rowl[r] * g.ldz + dp->z_off + n0) = v;
                 } else {
                     if (row_ok[r] && n0 < dp->a8) {
-                        v += *(gc4)((gcf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0);
-                        if (g.tap) *(g4)((gf)g.tap + (size_t)row[r] * g.ldt + dp->p_off + n0) = v;
-                        *(g4)((gf)g.Y + (size_t)row[r] * g.ldy + dp->p_off + n0) = v * *(gc4)((gcf)g.Xmul + (size_t)row[r] * g.ldm + dp->p_off + n0);
+                        v += *(gc4)((gcf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0);
+                        if (g.tap) *(g4)((gf)g.tap + (size_t)rowl[r] * g.ldt + dp->p_off + n0) = v;
+                        *(g4)((gf)g.Y + (size_t)rowl[r] * g.ldy + dp->p_off + n0) = v * *(gc4)((gcf)g.Xmul + (size_t)rowl[r] * g.ldm + dp->p_off + n0);
                     }
                 }
             }
@@ -584,6 +590,12 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
 
     auto layer = [&](auto last_tag, const int l) {
         constexpr bool last = decltype(last_tag)::value;
+        // the rows of this workgroup again, behind an opaque asm: the global addresses of the epilogue below are then formed
+        // here, per layer - as loop invariants the compiler computed all of them (14 64-bit pointers) once, in front of the
+        // layer loop, and kept them in scratch (the only scratch use of the kernel, reloaded every layer)
+        int rowl[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) { rowl[r] = row[r]; asm volatile("" : "+v"(rowl[r])); }
         int K32, cnt; gcc wp;
         layer_stream(l, K32, cnt, wp);
         const int boff = dp->L[l].bias_off;
@@ -604,8 +616,8 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                     const int nn = (n0 < dp->a8 && (tt == 0 || two)) ? n0 : 0;
 #pragma unroll
                     for (int r = 0; r < RT; ++r) {
-                        rv[tt][r] = *(gc4)((gcf)g.P + (size_t)row[r] * g.ldp + dp->p_off + nn);
-                        mv[tt][r] = *(gc4)((gcf)g.Xmul + (size_t)row[r] * g.ldm + dp->p_off + nn);
+                        rv[tt][r] = *(gc4)((gcf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + nn);
+                        mv[tt][r] = *(gc4)((gcf)g.Xmul + (size_t)rowl[r] * g.ldm + dp->p_off + nn);
                     }
                 }
             }
@@ -688,14 +700,14 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                     split4(v, p0, p1);
                     held[last ? 0 : c + tt][r][0] = p0;
                     held[last ? 0 : c + tt][r][NPL - 1] = NPL == 2 ? p1 : p0;
-                    if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)row[r] * g.ldp + dp->p_off + n0) = v;
+                    if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0) = v;
                 } else if (CHAIN == CHAIN_SPLIT) {
-                    if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)row[r] * g.ldz + dp->z_off + n0) = v;
+                    if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)rowl[r] * g.ldz + dp->z_off + n0) = v;
                 } else {
                     if (row_ok[r] && n0 < dp->a8) {
                         v += rv[tt][r];                                              // mask = residual + post(...)   bsrnn.py:425
-                        if (g.tap) *(g4)((gf)g.tap + (size_t)row[r] * g.ldt + dp->p_off + n0) = v;
-                        *(g4)((gf)g.Y + (size_t)row[r] * g.ldy + dp->p_off + n0) = v * mv[tt][r];   // x * mask   bsrnn.py:441
+                        if (g.tap) *(g4)((gf)g.tap + (size_t)rowl[r] * g.ldt + dp->p_off + n0) = v;
+                        *(g4)((gf)g.Y + (size_t)rowl[r] * g.ldy + dp->p_off + n0) = v * mv[tt][r];   // x * mask   bsrnn.py:441
                     }
                 }
             }

@@ -65,3 +65,34 @@ def test_packed_fp32_only_in_kernels_that_issue_mfma(tmp_path):
         n_pk += sum(1 for v in stats.values() if v[1])
     # the disassembly worked: the DSP kernels are there, and the GEMM split / LSTM cells do use packed fp32
     assert n_kernels > 20 and n_pk > 0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")), reason="llvm-readelf of the ROCm toolchain not found")
+def test_no_kernel_uses_scratch(tmp_path):
+    """No shipped kernel spills registers or keeps arrays in scratch memory.  Round 3: the time-axis kernel's instantiation with 9-14
+    spilled registers (reloaded inside its loops) returned a result a few ulp off about once in 40 calls when a call ran beside the
+    first kernels of a second process - never alone, never in the steady state beside a running load, and not at all once the kernel
+    fitted its 128 VGPRs (NOTEBOOK.md R3.11, profiles/r03_busy_start.txt).  Whether scratch itself is fragile there is not established;
+    the rule costs nothing: every kernel of the library fits its register budget."""
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    readelf = os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")
+    n = 0
+    offenders = []
+    for i, (triple, data) in enumerate(device_code_objects(LIB)):
+        if "gfx950" not in triple or not data:
+            continue
+        f = tmp_path / ("dev%d.co" % i)
+        f.write_bytes(data)
+        notes = subprocess.run([readelf, "--notes", str(f)], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+            spilled = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))      # (SGPR spills go to VGPR lanes, not to memory)
+            dynamic = re.search(r"\.uses_dynamic_stack:\s+(\w+)", blk).group(1)
+            n += 1
+            if scratch or spilled or dynamic != "false":
+                offenders.append((name, scratch, spilled, dynamic))
+    assert n > 20, "no kernel metadata found"
+    assert not offenders, "kernels with scratch / spills: %s" % offenders[:5]
