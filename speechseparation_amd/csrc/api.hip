@@ -975,17 +975,26 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             else if (img <= CHAIN_LDS_EX) { RT = 1; GR = 1; }
             // the widest bands (32 rows would be all the LDS holds): 48 rows on 16 x 16 x 32 MFMAs instead (chain_body48); there the
             // layer fields count k-steps of 32 and feature tiles of 16
+            // ... and bands of the 64-row class whose image leaves room for FIVE row tiles of 16 and whose feature tiles of 16 are at most
+            // three per wave (the 384-wide band: 24 tiles = 3 x 8 where the 32 x 32 geometry has twelve tiles for eight waves): 80 rows
+            // per weight fragment instead of 64, every wave busy (BSRNN_CHAIN_NO80=1 keeps them on the 32 x 32 geometry)
             bool g48 = false;
-            if (RT == 1 && GR == 1 && !getenv("BSRNN_CHAIN_NO48")) {
+            const bool no48 = getenv("BSRNN_CHAIN_NO48") != nullptr;
+            const bool try48 = RT == 1 && GR == 1 && !no48;
+            const bool try80 = RT == 2 && GR == 1 && !no48 && !getenv("BSRNN_CHAIN_NO80");
+            if (try48 || try80) {
+                const int rt16 = try48 ? 3 : 5, ctr = try48 ? 6 : 3;
                 int u48 = 0, maxft = 0, nb48 = 0;
+                bool whole = true;                                   // every layer's width a multiple of 16 (no ragged tile of 16)
                 for (int l = 0; l < CHAIN_LAYERS; ++l) {
                     const int K32 = (ld[l].Kd + 31) / 32, FT = (ld[l].N + 15) / 16;
                     u48 = imax(u48, 4 * K32);
                     if (l + 1 < CHAIN_LAYERS) u48 = imax(u48, 2 * FT);
                     maxft = imax(maxft, FT); nb48 += 16 * FT;
+                    whole = whole && ld[l].N % 16 == 0;
                 }
-                if (2 * u48 * 48 * 16 <= CHAIN_LDS_EX && maxft <= 8 * 6 && nb48 * 4 <= CHAIN_LDS_BIAS) {
-                    g48 = true; RT = 3; units = u48; nbias = 0; cost = 0;
+                if (2 * u48 * (16 * rt16) * 16 <= CHAIN_LDS_EX && maxft <= 8 * ctr && nb48 * 4 <= CHAIN_LDS_BIAS && (try48 || (whole && maxft % 8 == 0))) {
+                    g48 = true; RT = rt16; GR = 1; units = u48; nbias = 0; cost = 0;
                     for (int l = 0; l < CHAIN_LAYERS; ++l) {
                         d.L[l].K16 = (ld[l].Kd + 31) / 32; d.L[l].NTL = (ld[l].N + 15) / 16;
                         d.L[l].bias_off = nbias; nbias += 16 * d.L[l].NTL;
@@ -1030,7 +1039,7 @@ int bsrnn_commit_params(bsrnn_ctx* c)
         if (!fused) break;
         // class = rows per workgroup (RT = 1, 2, 4, constant bands), heaviest band first inside a class
         std::stable_sort(built.begin(), built.end(), [](const Built& x, const Built& y) {
-            auto cls = [](const ChainDesc& d) { const int rows = chain_rows(d); return d.constant ? 4 : (rows <= 48 ? 0 : (rows == 64 ? 1 : (rows == 128 ? 2 : 3))); };
+            auto cls = [](const ChainDesc& d) { const int rows = chain_rows(d); return d.constant ? 4 : (rows <= 48 ? 0 : (rows <= 80 ? 1 : (rows == 128 ? 2 : 3))); };
             const int cx = cls(x.d), cy = cls(y.d);
             return cx != cy ? cx < cy : x.cost > y.cost;
         });

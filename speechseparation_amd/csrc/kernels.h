@@ -110,7 +110,7 @@ struct ChainLaunch {
     unsigned long long* dbg;         // measurement only (CHAIN_TRACE builds of tools/chain_bench.hip): per-wave phase stamps
 };
 // rows per workgroup of a descriptor (32 RT GR; 256 for a constant band)
-inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : (d.RT == 3 ? 48 : 32 * d.RT * (8 / d.NW)); }
+inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : (d.RT >= 3 ? 16 * d.RT : 32 * d.RT * (8 / d.NW)); }   // RT >= 3: row tiles of 16 (16 x 16 x 32 geometry: 48 or 80 rows)
 void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 
 // ------------------------------------------------------------------ dual-path LSTM kernels

@@ -495,16 +495,21 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
 //   B = activations:  lane (m = l & 15, kb)          holds x[m][32 ks + 8 kb + j]: LDS image [k / 8][48 rows][8], per piece
 //   D: lane (m, g = l >> 4), register e: feature 16 t + 4 g + e of row m - four consecutive features, as in chain_body.
 // In this geometry ChainLayer::K16 counts k-steps of 32 and ChainLayer::NTL feature tiles of 16.
-template <int CHAIN, int TERMS>
+// RT row tiles of 16 (48 rows: the 768-wide band; 80 rows: bands whose image leaves room for five - the 384-wide band, 24 feature
+// tiles = three per wave where the 32 x 32 geometry had twelve tiles for eight waves and 64 rows per weight fragment), CTR = feature
+// tiles per wave the held-tile registers are sized for, PDR = k-steps of weight fragments in flight.
+template <int CHAIN, int TERMS, int RT = 3, int CTR = 6, int PDR = CHAIN_PD48, int TP = 2>
 __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDesc* const dp, const int row0, char* const smem)
 {
     constexpr int NPL = TERMS == 1 ? 1 : 2;
-    constexpr int NW = 8, RT = 3, ROWS = 48, CTR = 6, UB = ROWS * 16;      // UB: bytes of one k-unit (8 k) of one piece
-    constexpr int PDR = CHAIN_PD48;               // k-steps in flight; a step is TWO feature tiles' fragments (4 KB per wave)
-    constexpr int TP = 2;                         // feature tiles per pass over K: each activation fragment read from LDS
-                                                  // feeds both (LDS read bandwidth is the co-bottleneck of 16 x 16 tiles)
+    constexpr int NW = 8, ROWS = 16 * RT, UB = ROWS * 16;      // UB: bytes of one k-unit (8 k) of one piece
+                                                  // (PDR k-steps in flight; a step is TWO feature tiles' fragments, 4 KB per wave)
+    // TP: feature tiles per pass over K: each activation fragment read from LDS feeds TP tiles (LDS read bandwidth is the
+    // co-bottleneck of 16 x 16 tiles)
     float* const sbias = reinterpret_cast<float*>(smem + CHAIN_LDS_EX);
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));            // this body's own copy (a shared one lives - and at 256 VGPRs spills - across all bodies)
+    const int tid = tid_, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, gq = lane >> 4;
     const int M = g.M;
@@ -593,9 +598,16 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
         // the rows of this workgroup again, behind an opaque asm: the global addresses of the epilogue below are then formed
         // here, per layer - as loop invariants the compiler computed all of them (14 64-bit pointers) once, in front of the
         // layer loop, and kept them in scratch (the only scratch use of the kernel, reloaded every layer)
+        // (and recomputed from row0, so that neither the row indices nor their validity live in registers across the layers)
         int rowl[RT];
+        bool rokl[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) { rowl[r] = row[r]; asm volatile("" : "+v"(rowl[r])); }
+        for (int r = 0; r < RT; ++r) {
+            int rr = row0 + 16 * r + m;
+            asm volatile("" : "+v"(rr));
+            rokl[r] = rr < M;
+            rowl[r] = rokl[r] ? rr : M - 1;
+        }
         int K32, cnt; gcc wp;
         layer_stream(l, K32, cnt, wp);
         const int boff = dp->L[l].bias_off;
@@ -608,8 +620,12 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
             const bool two = c + 1 < cnt;                         // wave-uniform: the pass has a second tile
             const gcc tp = wp + (size_t)c * K32 * STEP;
             const bool more = c + TP < cnt, more_two = c + TP + 1 < cnt;
+            // the mask chain's last layer adds the residual P and multiplies the spectrum: with three row tiles the rows are requested
+            // in front of the K loop; with five their 80 registers do not fit beside the accumulators and the fragments, so they are
+            // requested when the K loop is through (its fragment registers are free then)
+            constexpr bool PRE_RM = RT <= 3;
             v4f rv[TP][RT], mv[TP][RT];
-            if (CHAIN == CHAIN_MASK && last) {
+            auto load_rm = [&]() {
 #pragma unroll
                 for (int tt = 0; tt < TP; ++tt) {
                     const int n0 = 16 * (wn + NW * (c + tt)) + 4 * gq;
@@ -620,7 +636,8 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                         mv[tt][r] = *(gc4)((gcf)g.Xmul + (size_t)rowl[r] * g.ldm + dp->p_off + nn);
                     }
                 }
-            }
+            };
+            if (CHAIN == CHAIN_MASK && last && PRE_RM) load_rm();
             v4f hi[TP][RT], lo[TP][RT];
 #pragma unroll
             for (int tt = 0; tt < TP; ++tt)
@@ -679,6 +696,7 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                 }
             }
             // ---- the tiles' epilogue
+            if (CHAIN == CHAIN_MASK && last && !PRE_RM) load_rm();
 #pragma unroll
             for (int tt = 0; tt < TP; ++tt) {
             if (tt == 1 && !two) break;
@@ -700,11 +718,11 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                     split4(v, p0, p1);
                     held[last ? 0 : c + tt][r][0] = p0;
                     held[last ? 0 : c + tt][r][NPL - 1] = NPL == 2 ? p1 : p0;
-                    if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0) = v;
+                    if (to_p && rokl[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0) = v;
                 } else if (CHAIN == CHAIN_SPLIT) {
-                    if (row_ok[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)rowl[r] * g.ldz + dp->z_off + n0) = v;
+                    if (rokl[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)rowl[r] * g.ldz + dp->z_off + n0) = v;
                 } else {
-                    if (row_ok[r] && n0 < dp->a8) {
+                    if (rokl[r] && n0 < dp->a8) {
                         v += rv[tt][r];                                              // mask = residual + post(...)   bsrnn.py:425
                         if (g.tap) *(g4)((gf)g.tap + (size_t)rowl[r] * g.ldt + dp->p_off + n0) = v;
                         *(g4)((gf)g.Y + (size_t)rowl[r] * g.ldy + dp->p_off + n0) = v * mv[tt][r];   // x * mask   bsrnn.py:441
@@ -767,12 +785,15 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
     (void)RT; (void)GR;
     return;
 #endif
-    if (RT == 3) chain_body48<CHAIN, TERMS>(g, dp, row0, smem);
-    else if (GR == 8) chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem);
-    else if (RT == 1 && GR == 1) chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem);
-    else if (RT == 2 && GR == 1) chain_body<CHAIN, TERMS, 2, 1>(g, dp, row0, smem);
-    else if (RT == 2 && GR == 2) chain_body<CHAIN, TERMS, 2, 2>(g, dp, row0, smem);
-    else chain_body<CHAIN, TERMS, 1, 4>(g, dp, row0, smem);
+    // (every geometry ends in `return`: with an else-if chain and one join the structurizer lays the bodies out one behind the other
+    //  and keeps values of the later ones - the thread index, for one - alive through the earlier ones' loops: spills at 256 VGPRs)
+    if (RT == 3) { chain_body48<CHAIN, TERMS>(g, dp, row0, smem); return; }
+    if (RT == 5) { chain_body48<CHAIN, TERMS, 5, 3, 2, (CHAIN == CHAIN_SPLIT ? 1 : 2)>(g, dp, row0, smem); return; }
+    if (GR == 8) { chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem); return; }
+    if (RT == 1 && GR == 1) { chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem); return; }
+    if (RT == 2 && GR == 1) { chain_body<CHAIN, TERMS, 2, 1>(g, dp, row0, smem); return; }
+    if (RT == 2 && GR == 2) { chain_body<CHAIN, TERMS, 2, 2>(g, dp, row0, smem); return; }
+    chain_body<CHAIN, TERMS, 1, 4>(g, dp, row0, smem);
 }
 
 void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream)

@@ -94,9 +94,10 @@ def test_fused_chains_equal_the_per_layer_flow_bit_for_bit(kind, no48):
     """The fused chain kernel (mlp_chain.hip, the default) multiplies the same fp16 pieces in the same k order as the
     per-layer launches (BSRNN_MLP=layers) wherever it uses the same 32 x 32 x 16 MFMA: separate(), forward (output and
     mask) and a chunk with state must be EQUAL, for the 12-band table (geometries of 32 / 64 / 128 / 256 rows per
-    workgroup, ragged row counts; BSRNN_CHAIN_NO48 keeps its 768-wide band on the 32 x 32 geometry, BSRNN_CHAIN_RAG=0 the
-    514-wide band's last feature tile on one wave instead of split over the k-steps of eight) and the 41-band table."""
-    extra = {"BSRNN_CHAIN_NO48": "1", "BSRNN_CHAIN_RAG": "0"} if no48 else {}
+    workgroup, ragged row counts; BSRNN_CHAIN_NO48 keeps its 768- and 384-wide bands on the 32 x 32 geometry, BSRNN_CHAIN_RAG=0 the
+    514-wide band's last feature tile on one wave instead of split over the k-steps of eight) and the 41-band table (BSRNN_CHAIN_NO80:
+    none of its bands on the 80-row 16 x 16 geometry)."""
+    extra = {"BSRNN_CHAIN_NO48": "1", "BSRNN_CHAIN_RAG": "0"} if no48 else {"BSRNN_CHAIN_NO80": "1"}
     with tempfile.TemporaryDirectory() as d:
         out_f, fused = run_child(kind, extra, d, "fused")
         out_l, layers = run_child(kind, dict(extra, BSRNN_MLP="layers"), d, "layers")
@@ -106,8 +107,8 @@ def test_fused_chains_equal_the_per_layer_flow_bit_for_bit(kind, no48):
 
 
 def test_48_row_geometry_of_the_widest_band_is_at_rounding_level():
-    """By default the 768-wide band runs 48 rows per workgroup on v_mfma_f32_16x16x32_f16 (the same products, summed 32
-    instead of 16 per instruction) and the last two columns of the 514-wide band are summed as eight k-slices (one per
+    """By default the 768-wide band runs 48 rows and the 384-wide band 80 rows per workgroup on v_mfma_f32_16x16x32_f16 (the same
+    products, summed 32 instead of 16 per instruction) and the last two columns of the 514-wide band are summed as eight k-slices (one per
     wave): not bit-identical to the 32 x 32 x 16 per-layer kernels - but at fp32 rounding level
     (last-bit differences of Z pass through the four recurrent blocks: 5e-7 ... 3e-6 of the range observed, bound 1e-5,
     a tenth of the parity tolerance)."""

@@ -64,9 +64,21 @@ int main(int argc, char** argv)
         else if (4 * img <= CHAIN_LDS_EX && maxntl <= 12) { RT = 2; GR = 2; }
         else if (2 * img <= CHAIN_LDS_EX) { RT = 2; GR = 1; }
         if (getenv("CHAIN_GEOM")) sscanf(getenv("CHAIN_GEOM"), "%d,%d", &RT, &GR);      // override (must fit the LDS)
-        const bool g48 = RT == 1 && GR == 1 && !getenv("BSRNN_CHAIN_NO48");
+        const bool try48 = RT == 1 && GR == 1 && !getenv("BSRNN_CHAIN_NO48");
+        bool try80 = RT == 2 && GR == 1 && !getenv("BSRNN_CHAIN_NO48") && !getenv("BSRNN_CHAIN_NO80");
+        if (try80) {                                    // as api.hip: five row tiles of 16 where they fit and the tiles of 16 are 3 x 8 at most
+            int u = 0, maxft = 0; bool whole = true;
+            for (int l = 0; l < 5; ++l) {
+                const int N = chain ? dims_m[l][0] : dims_s[l][0], Kd = chain ? dims_m[l][1] : dims_s[l][1];
+                u = std::max(u, 4 * ((Kd + 31) / 32));
+                if (l < 4) u = std::max(u, 2 * ((N + 15) / 16));
+                maxft = std::max(maxft, (N + 15) / 16); whole = whole && N % 16 == 0;
+            }
+            try80 = 2 * u * 80 * 16 <= CHAIN_LDS_EX && maxft <= 24 && whole && maxft % 8 == 0;
+        }
+        const bool g48 = try48 || try80;
         if (g48) {
-            RT = 3; units = 0; nbias = 0;
+            RT = try48 ? 3 : 5; GR = 1; units = 0; nbias = 0;
             for (int l = 0; l < 5; ++l) {
                 const int N = chain ? dims_m[l][0] : dims_s[l][0], Kd = chain ? dims_m[l][1] : dims_s[l][1];
                 d.L[l].K16 = (Kd + 31) / 32; d.L[l].NTL = (N + 15) / 16; d.L[l].bias_off = nbias; nbias += 16 * d.L[l].NTL;
@@ -91,12 +103,12 @@ int main(int argc, char** argv)
             else pack_chain_layer_host(w.data(), N, Kd, Kd, d.NW, 2, bu.w, d.L[l].rag);
             for (int n = 0; n < N; ++n) bu.b[d.L[l].bias_off + n] = 0.1f * frand(seed);
         }
-        wbytes_per_tile += g48 ? bu.w.size() * 2 * 32 / 48 : bu.w.size() * 2 / d.RT;      // per 32 rows: a wave group streams the weights once for its rows
+        wbytes_per_tile += g48 ? bu.w.size() * 2 * 32 / (16 * d.RT) : bu.w.size() * 2 / d.RT;      // per 32 rows: a wave group streams the weights once for its rows
         printf("band %2d a=%4d  NW=%d RT=%d  units=%3d  weights %.2f MB  cost %ld\n", i, a, d.NW, d.RT, units, bu.w.size() * 2 / 1e6, bu.cost);
         built.push_back(std::move(bu));
     }
     std::stable_sort(built.begin(), built.end(), [](const Built& x, const Built& y) {
-        auto cls = [](const ChainDesc& d) { const int r = chain_rows(d); return r <= 48 ? 0 : (r == 64 ? 1 : (r == 128 ? 2 : 3)); };
+        auto cls = [](const ChainDesc& d) { const int r = chain_rows(d); return r <= 48 ? 0 : (r <= 80 ? 1 : (r == 128 ? 2 : 3)); };
         const int cx = cls(x.d), cy = cls(y.d);
         return cx != cy ? cx < cy : x.cost > y.cost;
     });
