@@ -112,6 +112,8 @@ struct bsrnn_ctx {
     size_t cap_rows = 0;
     float* d_ws = nullptr;
     float *Xf, *Yf, *A1, *A2, *P, *Z0, *Z1, *HB0, *HB1, *H1;
+    int* band_flags = nullptr;      // band_pair_h2_kernel's hand-over flags (2 per tile of 16 frame rows + slack per row block), zero at allocation
+    bool band_pair_off = false;     // a pair launch reported that its partner workgroups did not meet (value 4): one launch per layer from then on
     size_t tap_rows = 0;
     float* d_tap = nullptr;
 
@@ -298,8 +300,9 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
     if (c->d_ws) { HIP_TRY(hipFree(c->d_ws)); c->d_ws = nullptr; c->cap_rows = 0; }
     const size_t KH = (size_t)c->K * HID;
     auto seg = [](size_t n) { return (n + 63) & ~size_t(63); };
-    const size_t sizes[10] = {seg(rows * c->LDP), seg(rows * c->LDP), seg(rows * c->LDA), seg(rows * c->LDA), seg(rows * c->LDP),
-                              seg(rows * KH), seg(rows * KH), seg(rows * KH * 2), seg(rows * KH * 2), seg(rows * KH)};
+    const size_t sizes[11] = {seg(rows * c->LDP), seg(rows * c->LDP), seg(rows * c->LDA), seg(rows * c->LDA), seg(rows * c->LDP),
+                              seg(rows * KH), seg(rows * KH), seg(rows * KH * 2), seg(rows * KH * 2), seg(rows * KH),
+                              seg(rows / 8 + 2 * MAX_PARTS + 64)};
     size_t total = 0;
     for (size_t s : sizes) total += s;
     HIP_TRY(hipMalloc((void**)&c->d_ws, total * sizeof(float)));
@@ -309,6 +312,7 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
     float* p = c->d_ws;
     float** dst[10] = {&c->Xf, &c->Yf, &c->A1, &c->A2, &c->P, &c->Z0, &c->Z1, &c->HB0, &c->HB1, &c->H1};
     for (int i = 0; i < 10; ++i) { *dst[i] = p; p += sizes[i]; }
+    c->band_flags = reinterpret_cast<int*>(p);
     c->cap_rows = rows;
     ++c->gen;
     return 0;
@@ -410,6 +414,7 @@ struct Part {
     hipStream_t s;
     const float* Xf; float* Yf; float* tap;              // [C*T][LDP], band-padded spectrum layout
     float *A1, *A2, *P, *Z0, *Z1, *HB0, *HB1, *H1;
+    int* band_flags;                                     // this part's hand-over flags of the band-pair launch
     const float* state_in; float* state_out;             // [4][2][C_total*K][64] slabs already offset to this part's first row
     size_t state_slab;                                   // floats between the two Time blocks' slabs (uses C_total)
     const float* wave; float* wave_out; int64_t n;       // only for the fused sandwich
@@ -425,8 +430,14 @@ Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s)
     p.A1 = c->A1 + m0 * c->LDA; p.A2 = c->A2 + m0 * c->LDA; p.P = c->P + m0 * c->LDP;
     p.Z0 = c->Z0 + m0 * KH; p.Z1 = c->Z1 + m0 * KH; p.H1 = c->H1 + m0 * KH;
     p.HB0 = c->HB0 + m0 * KH * 2; p.HB1 = c->HB1 + m0 * KH * 2;
+    p.band_flags = c->band_flags + 2 * (m0 / 16) + 2 * (row0 ? 1 + row0 % MAX_PARTS : 0);      // (row blocks never share a flag pair)
     return p;
 }
+
+// the band blocks' fc in parts needs the pair launch (lstm.hip); a context whose pair launch once reported that its partner workgroups
+// did not meet runs the round-2 flow from then on
+static bool ctx_parts(const bsrnn_ctx* c) { return band_fc_in_parts() && !c->band_pair_off; }
+static bool ctx_pair(const bsrnn_ctx* c) { return band_pair_enabled() && !c->band_pair_off; }
 
 enum { MS_STFT, MS_BANDSPLIT, MS_BAND0, MS_BANDFC0, MS_TIME0, MS_TIMEFC0, MS_BAND1, MS_BANDFC1, MS_TIME1, MS_TIMEFC1, MS_MASK, MS_ISTFT, MS_COUNT };
 
@@ -469,16 +480,20 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         }
         // parts flow (band_fc_in_parts()): block 0 reads Z0 and its time block writes Z1, block 1 reads Z1 and its time block writes
         // Z0 - the block's fc + residual are formed inside the two launches around them (kernels.h), MS_BANDFC does not exist
-        const bool parts = band_fc_in_parts();
+        const bool parts = ctx_parts(c);
         const float* zi = parts && blk ? p.Z1 : p.Z0;
+        if (ctx_pair(c)) {                        // both layers in one launch (A/B: BSRNN_BAND_PAIR=0)
+            launch_band_pair(zi, p.HB0, p.HB1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1], M, K, c->d_range, s,
+                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags);
+            break;
+        }
         launch_band_lstm(zi, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
-        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s,
-                         parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr);
+        launch_band_lstm(p.HB0, p.HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s);
         break;
     }
     case MS_BANDFC0: case MS_BANDFC1: {
         const int blk = stage == MS_BANDFC1;
-        if (band_block_is_small(M, K) || band_fc_in_parts()) break;     // done inside the band launch / inside the launches around it
+        if (band_block_is_small(M, K) || ctx_parts(c)) break;     // done inside the band launch / inside the launches around it
         StageScope sc(c, ST_BAND_FC, s);
         gemm_slot(c, BLK_FC0 + 2 * blk, p.HB1, 2 * HID, p.Z1, HID, p.Z0, HID, nullptr, 0, nullptr, M * K, EPI_RES, s);
         break;
@@ -488,7 +503,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         StageScope sc(c, ST_TIME_LSTM, s);
         // fp16x2 mode: the launch also computes the block's fc + residual (out = fc(h1) + Z1 -> Z0); otherwise it writes h1
         const bool fused = time_lstm_fuses_fc();
-        if (band_fc_in_parts() && !band_block_is_small(M, K)) {
+        if (ctx_parts(c) && !band_block_is_small(M, K)) {
             launch_time_lstm(blk ? p.Z1 : p.Z0, blk ? p.Z0 : p.Z1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
                              p.state_in ? p.state_in + blk * p.state_slab : nullptr,
                              p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, c->d_range, s,
@@ -561,6 +576,11 @@ int check_range(bsrnn_ctx* c)
         const int v = *(volatile int*)c->h_range;
         *(volatile int*)c->h_range = 0;
         if (v == 3) return fail(BSRNN_EHIP, "an earlier time-axis LSTM launch gave up waiting on its own workgroup-local counters (internal error)");
+        if (v == 4) {
+            c->band_pair_off = true;
+            return fail(BSRNN_EHIP, "an earlier band-axis launch (both layers in one launch, range policy 'deferred') did not find its partner workgroups on the "
+                                    "same XCD in time; its results are invalid - repeat the call (the context now runs one launch per layer)");
+        }
         return fail(BSRNN_ERANGE, "an earlier call (range policy 'deferred') fed the fp16x2 matrix path an activation beyond +-65504; its "
                                   "results are invalid - repeat it under the default policy, rescale the input or set BSRNN_GEMM=f32 BSRNN_LSTM=f32");
     }
@@ -579,6 +599,15 @@ int finish_call(bsrnn_ctx* c, hipStream_t s, F&& rerun)
     if (!v) return 0;
     *(volatile int*)c->h_range = 0;
     if (v == 3) return fail(BSRNN_EHIP, "the time-axis LSTM launch gave up waiting on its own workgroup-local counters (internal error)");
+    if (v == 4) {                                 // the band-pair launch's partners did not meet (placement / dispatch order not as assumed): the
+        c->band_pair_off = true;                  // same call again with one launch per layer, same arithmetic; pairing stays off for this context
+        if (int rc4 = rerun()) return rc4;
+        HIP_TRY(hipStreamSynchronize(s));
+        const int v4 = *(volatile int*)c->h_range;
+        if (!v4) return 0;
+        *(volatile int*)c->h_range = 0;
+        if (v4 == 3 || v4 == 4) return fail(BSRNN_EHIP, "a recurrent launch gave up waiting on its partners (internal error)");
+    }
     set_force_f32(true);
     const int rc = rerun();
     set_force_f32(false);
@@ -1346,12 +1375,11 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
         if (band_block_is_small(M, K)) {
             launch_band_block_small(c->Z0, c->Z1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1],
                                     c->bandFc16[blk], c->bandFcB[blk], M, K, c->d_range, s);
-        } else if (band_fc_in_parts()) {           // the block's fc + residual inside the launches around it (run_stage, kernels.h)
+        } else if (ctx_parts(c)) {                 // the block's fc + residual inside the launches around it (run_stage, kernels.h)
             float* zi = blk ? c->Z1 : c->Z0;
             float* zo = blk ? c->Z0 : c->Z1;
-            launch_band_lstm(zi, c->HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
-            launch_band_lstm(c->HB0, c->HB1, c->bandW[blk][1], c->bandW16[blk][1], c->bandB[blk][1], M, K, 128, c->d_range, s,
-                             c->bandFc16[blk], c->bandFcB[blk]);
+            launch_band_pair(zi, c->HB0, c->HB1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1], M, K, c->d_range, s,
+                             c->bandFc16[blk], c->bandFcB[blk], c->band_flags);
             launch_time_lstm(zi, zo, c->timeW[blk], c->timeW16[blk], c->timeB[blk], state_in ? state_in + blk * slab : nullptr,
                              state_out ? state_out + blk * slab : nullptr, C, T, K, c->d_range, s, c->timeFc16[blk], c->timeFcB[blk], c->HB1);
             continue;

@@ -124,13 +124,17 @@ void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 //   wpk  packed [2 dir][4 wave][(IN+64)/4 step][4 gate][64 lane], bias [2][256]
 //   wpk16 (LSTM_FP16X2): the same matrix as two fp16 pieces in the f16 MFMA's B-operand order,
 //         [2 dir][4 wave][(IN+64)/32 blk][4 gate][2 piece][64 lane][8]
-//   fc16 / fcb (LSTM_FP16X2, IN = 128, optional): the block's fc (128 -> 64) as launch_band_block_small takes it.  When given, hout
-//        receives, instead of h, the two directions' SHARES of fc(h): hout[n][t][dir * 64 + f] = sum_k W_fc[f][dir * 64 + k] h_dir[n][t][k]
-//        (+ b[f] in the forward half); the time-axis launch adds the halves and the residual (`part` of launch_time_lstm), so the
-//        block's fc launch disappears.  band_fc_in_parts() says whether api.hip runs the blocks that way.
 void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      int N, int L, int IN, int* range_flag, hipStream_t stream, const void* fc16 = nullptr, const float* fcb = nullptr);
+                      int N, int L, int IN, int* range_flag, hipStream_t stream);
+// The block's fc in parts (BSRNN_BAND_FC): with fc16 / fcb the pair launch below writes to hb1, instead of h, the two directions' SHARES
+// of fc(h): hb1[n][t][dir * 64 + f] = sum_k W_fc[f][dir * 64 + k] h_dir[n][t][k] (+ b[f] in the forward half); the time-axis launch
+// adds the halves and the residual (`part` of launch_time_lstm), so the block's fc launch disappears.
 bool band_fc_in_parts();
+// Both layers of a band block in one launch (lstm.hip::band_pair_h2_kernel): flags = 2 ints per tile of 16 sequences, zero before the
+// first launch and otherwise only touched by these launches.
+bool band_pair_enabled();
+void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
+                      int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags);
 // The whole band-axis block (both layers, both directions, fc + residual) of a few sequences in one workgroup: the streaming
 // step's N = C frame rows.  w0pk16 / w1pk16 / bias0 / bias1 are launch_band_lstm's arguments of the two layers; fc16 the block's
 // fc (128 -> 64) as fp16x2 B fragments [4 tile][4 blk][2 piece][64 lane][8], fcb its bias.  zout = fc(h1) + b + zin.

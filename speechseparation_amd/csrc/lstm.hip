@@ -222,11 +222,25 @@ __device__ __forceinline__ void split_h2(float v, _Float16& p0, _Float16& p1)
 // forward half), and the consumer (the time-axis kernel's staging) adds the two halves and the residual - the grouped-GEMM launch
 // of the block's fc, its 100 MB of traffic and its 18 us are gone.  The product is formed where h_{t} is read back as the next
 // step's B operand anyway: 6 more MFMAs per wave and step on the fragments already in registers, the fc's A fragments from LDS.
-template <int IN, bool TRACE = false, bool PART = false>
-__global__ __launch_bounds__(256, (IN == 64 ? BAND_OCC64 : 2)) void band_lstm_h2_kernel(const float* __restrict__ xin, float* __restrict__ hout,
-                                                              const uint4* __restrict__ wpk, const float* __restrict__ bias,
-                                                              int N, int L, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
-                                                              const uint4* __restrict__ wfc = nullptr, const float* __restrict__ bfc = nullptr)
+// LDS of one band layer: [x planes 2 slots][h planes 2 slots][second-piece weight blocks][bias][fc fragments]
+template <int IN, bool PART>
+struct BandLds {
+    static constexpr int NLDS = IN == 128 ? BAND_NLDS : BAND_NLDS64;
+    static constexpr int XPL = 0;
+    static constexpr int HPL = XPL + 2 * 2 * IN * 16 * 2;
+    static constexpr int W2 = HPL + 2 * 2 * HID * 16 * 2;
+    static constexpr int BIAS = W2 + (NLDS ? 4 * NLDS * 4 * 64 : 1) * 16;
+    static constexpr int FC = BIAS + (4 * HID + HID) * 4;          // gate biases [4][64] + the fc bias of the forward share [64]
+    static constexpr int BYTES = FC + (PART && !(PART_DBG & 2) ? 4 * 2 * 2 * 64 : 1) * 16;
+};
+
+// One layer of one (tile of 16 sequences, direction): the body of band_lstm_h2_kernel and of both phases of band_pair_h2_kernel.
+template <int IN, bool TRACE, bool PART>
+__device__ __forceinline__ void band_layer_body(char* const lds, const int dir, const int tile,
+                                                const float* __restrict__ xin, float* __restrict__ hout,
+                                                const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                int N, int L, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
+                                                const uint4* __restrict__ wfc, const float* __restrict__ bfc)
 {
     static_assert(!PART || IN == 2 * HID, "the fc share is formed by the second layer");
     // measurement only (TRACE, tools/lstm_h2_trace.hip): 100 MHz stamps per phase, accumulated per wave
@@ -241,22 +255,12 @@ __global__ __launch_bounds__(256, (IN == 64 ? BAND_OCC64 : 2)) void band_lstm_h2
     // compiles without scratch at 242 VGPRs (measured with spills: 1.9 us of every 3.5 us step in reloads)
     constexpr int NLDS = IN == 128 ? BAND_NLDS : BAND_NLDS64;
     constexpr int XV = IN / 64;                  // 16-byte units per thread per x tile
-    __shared__ __attribute__((aligned(16))) _Float16 xpl[2][2][IN * 16];     // [slot][piece][k / 8][seq][8]
-    __shared__ __attribute__((aligned(16))) _Float16 hpl[2][2][HID * 16];
-    __shared__ __attribute__((aligned(16))) uint4 w2lds[NLDS ? 4 * NLDS * 4 * 64 : 1];
-    __shared__ __attribute__((aligned(16))) float bias_lds[4 * HID];         // this direction's b_ih + b_hh, [gate][unit]
-    __shared__ __attribute__((aligned(16))) uint4 fclds[PART && !(PART_DBG & 2) ? 4 * 2 * 2 * 64 : 1];   // fc A fragments [wave][k block][piece][lane]
-
-    // Workgroup -> (tile of 16 sequences, direction).  The two directions of a tile read the same x rows: in the 1-D grid of
-    // launch_band_lstm they are 8 workgroup ids apart - the same XCD (id % 8), dispatched together - so the second read of a row
-    // is served by that XCD's L2 instead of a second trip to memory (2-D grids, the measurement tools': direction = blockIdx.y).
-    int dir = blockIdx.y, tile = blockIdx.x;
-    if (gridDim.y == 1) {
-        const int w = blockIdx.x & 15;
-        dir = w >> 3;
-        tile = (blockIdx.x >> 4) * 8 + (w & 7);
-        if (tile * 16 >= N) return;
-    }
+    using LD = BandLds<IN, PART>;
+    auto& xpl = *reinterpret_cast<_Float16 (*)[2][2][IN * 16]>(lds + LD::XPL);              // [slot][piece][k / 8][seq][8]
+    auto& hpl = *reinterpret_cast<_Float16 (*)[2][2][HID * 16]>(lds + LD::HPL);
+    uint4* const w2lds = reinterpret_cast<uint4*>(lds + LD::W2);
+    float* const bias_lds = reinterpret_cast<float*>(lds + LD::BIAS);                        // this direction's b_ih + b_hh, [gate][unit]
+    uint4* const fclds = reinterpret_cast<uint4*>(lds + LD::FC);                             // fc A fragments [wave][k block][piece][lane]
     const int n0 = tile * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
@@ -382,13 +386,13 @@ __global__ __launch_bounds__(256, (IN == 64 ? BAND_OCC64 : 2)) void band_lstm_h2
     };
     // PART: the fc share of the h whose fragments are in registers (features 16 wave + 4 q + r of sequence l15, like the gates)
     v4f fhi = zero4, flo = zero4;
-    v4f fbias = zero4;
-    if (PART && dir == 0) fbias = *reinterpret_cast<const v4f*>(bfc + 16 * wave + 4 * q);
+    const float* const fb_l = bias_lds + 4 * HID + 16 * wave + 4 * q;      // the share's bias from LDS (four registers the kernel does not have)
+    if (PART && tid < HID) bias_lds[4 * HID + tid] = dir == 0 ? bfc[tid] : 0.f;
     auto fc_mfma = [&](const int b, const h8v a0, const h8v a1) {
-        if (PART_DBG & 1) { fhi = fbias; flo = zero4; return; }
+        if (PART_DBG & 1) { fhi = *reinterpret_cast<const v4f*>(fb_l); flo = zero4; return; }
         const h8v f1 = __builtin_bit_cast(h8v, (PART_DBG & 2) ? w2lds[(wave * 4 + 2 * b) * 64 + lane] : fclds[(wave * 4 + 2 * b) * 64 + lane]);
         const h8v f2 = __builtin_bit_cast(h8v, (PART_DBG & 2) ? w2lds[(wave * 4 + 2 * b + 1) * 64 + lane] : fclds[(wave * 4 + 2 * b + 1) * 64 + lane]);
-        fhi = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, a0, b == 0 ? fbias : fhi, 0, 0, 0);
+        fhi = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, a0, b == 0 ? *reinterpret_cast<const v4f*>(fb_l) : fhi, 0, 0, 0);
         flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, a1, b == 0 ? zero4 : flo, 0, 0, 0);
         flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f2, a0, flo, 0, 0, 0);
     };
@@ -493,27 +497,119 @@ __global__ __launch_bounds__(256, (IN == 64 ? BAND_OCC64 : 2)) void band_lstm_h2
     }
 }
 
+// Workgroup -> (tile of 16 sequences, direction).  The two directions of a tile read the same x rows: in the 1-D grid of
+// launch_band_lstm they are 8 workgroup ids apart - the same XCD (id % 8), dispatched together - so the second read of a row
+// is served by that XCD's L2 instead of a second trip to memory (2-D grids, the measurement tools': direction = blockIdx.y).
+__device__ __forceinline__ bool band_tile_of_block(int N, int& dir, int& tile)
+{
+    dir = blockIdx.y; tile = blockIdx.x;
+    if (gridDim.y == 1) {
+        const int w = blockIdx.x & 15;
+        dir = w >> 3;
+        tile = (blockIdx.x >> 4) * 8 + (w & 7);
+    }
+    return tile * 16 < N;
+}
+
+template <int IN, bool TRACE = false, bool PART = false>
+__global__ __launch_bounds__(256, (IN == 64 ? BAND_OCC64 : 2)) void band_lstm_h2_kernel(const float* __restrict__ xin, float* __restrict__ hout,
+                                                              const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                              int N, int L, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
+                                                              const uint4* __restrict__ wfc = nullptr, const float* __restrict__ bfc = nullptr)
+{
+    __shared__ __attribute__((aligned(16))) char lds[BandLds<IN, PART>::BYTES];
+    int dir, tile;
+    if (!band_tile_of_block(N, dir, tile)) return;
+    band_layer_body<IN, TRACE, PART>(lds, dir, tile, xin, hout, wpk, bias, N, L, range_flag, dbg, wfc, bfc);
+}
+
+// Both layers of a band block in ONE launch.  A workgroup runs layer 0 of its (tile, direction), publishes its half of the fp16
+// planes and waits for its partner - the other direction of the same tile: 8 workgroup ids away, the same XCD, dispatched in the
+// same breath (launch_band_lstm's grid) - then runs layer 1 on both halves.  The hand-over goes through L2: every thread fences its
+// plane stores, one thread releases flags[2 tile + dir] = its old value + 1 (the pair's two flags count the launches over this tile in
+// lockstep: nothing to clear, nothing passed by value, so the launch can sit in a replayed graph) and polls the partner's flag, bounded; the reads of layer 1 come behind an acquire fence (L1 invalidated).  No deadlock: workgroups
+// are dispatched in id order, a waiting workgroup's partner is at most 8 ids behind it, and everything dispatched before a waiting
+// pair either is a complete pair or waits for partners that are dispatched before any later workgroup - so slots always free up.
+// One launch, one weight prologue (layer 1's 196 KB are requested before the wait) and one tail less per block; the planes are read
+// back from L2 while they are hot.
+template <bool PART>
+__global__ __launch_bounds__(256, 2) void band_pair_h2_kernel(const float* __restrict__ z, float* hb0, float* __restrict__ hb1,
+                                                              const uint4* __restrict__ w0, const float* __restrict__ b0,
+                                                              const uint4* __restrict__ w1, const float* __restrict__ b1,
+                                                              int N, int L, int* __restrict__ range_flag,
+                                                              const uint4* __restrict__ wfc, const float* __restrict__ bfc,
+                                                              int* flags)
+{
+    constexpr int B0 = BandLds<HID, false>::BYTES, B1 = BandLds<2 * HID, PART>::BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[B0 > B1 ? B0 : B1];
+    __shared__ int partner_ok;
+    int dir, tile;
+    if (!band_tile_of_block(N, dir, tile)) return;
+    band_layer_body<HID, false, false>(lds, dir, tile, z, hb0, w0, b0, N, L, range_flag, nullptr, nullptr, nullptr);
+    // Hand-over through the XCD's L2, which both workgroups share: a store is counted out of vmcnt when L2 has it, so vmcnt(0) is
+    // all the release this needs (an agent-scope release fence would write the whole L2 back for the sake of other XCDs: measured,
+    // 2.6x slower); the flag carries the XCC id so that a placement that breaks the assumption is reported, not computed with.
+    __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0): this thread's plane stores are in L2
+    __syncthreads();                              // ... every thread's; and nobody reads layer 0's LDS any more
+    if (threadIdx.x == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;      // HW_REG_XCC_ID[3:0]
+        // the pair's two flags count the launches that covered this tile, in lockstep: mine + 1 is this launch's number for both
+        const int epoch = ((__hip_atomic_load(&flags[2 * tile + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 4) + 1) & 0x7ffffff;
+        __hip_atomic_store(&flags[2 * tile + dir], (epoch << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, v;
+        while (((v = __hip_atomic_load(&flags[2 * tile + (dir ^ 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) break;       // (seconds: the partner never came - reported, not waited for)
+        }
+        partner_ok = (v >> 4) == epoch && (v & 15) == xcc;
+    }
+    __syncthreads();
+    if (!partner_ok) {                            // (value 4: api.hip runs the call again with one launch per layer and stops pairing)
+        if (threadIdx.x == 0 && range_flag) *range_flag = 4;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (orders the plane loads below behind the poll)
+    asm volatile("buffer_inv sc0" ::: "memory");                 // the partner's planes from L2, not from a line this CU's L1 may hold
+    band_layer_body<2 * HID, false, PART>(lds, dir, tile, hb0, hb1, w1, b1, N, L, range_flag, nullptr, wfc, bfc);
+}
+
+bool band_pair_enabled()
+{
+    static const bool on = [] { const char* e = getenv("BSRNN_BAND_PAIR"); return !(e && !strcmp(e, "0")); }();      // A/B: 0 = one launch per layer
+    return on && lstm_mode() == LSTM_FP16X2 && !force_f32();
+}
+// both layers of a band block as one launch (band_pair_h2_kernel); fc16 / fcb as launch_band_lstm's (shares of the fc) or null
+void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
+                      int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags)
+{
+    if (N <= 0 || L <= 0) return;
+    const dim3 grid((((N + 15) / 16 + 7) / 8) * 16), block(256);
+    if (fc16)
+        hipLaunchKernelGGL((band_pair_h2_kernel<true>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
+                           range_flag, (const uint4*)fc16, fcb, flags);
+    else
+        hipLaunchKernelGGL((band_pair_h2_kernel<false>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
+                           range_flag, (const uint4*)nullptr, (const float*)nullptr, flags);
+}
+
 // BSRNN_BAND_FC = part (default: the second band layer writes the two directions' shares of the block's fc, the time-axis launch adds
 // them and the residual while it stages its input) | gemm (the block's fc + residual as a grouped-GEMM launch, as in rounds 1-2)
 bool band_fc_in_parts()
 {
     static const bool on = [] { const char* e = getenv("BSRNN_BAND_FC"); return !(e && !strcmp(e, "gemm")); }();
-    return on && lstm_mode() == LSTM_FP16X2 && !force_f32() && time_lstm_fuses_fc();
+    // (the shares are formed by the pair launch only: the second layer alone with the shares sits at the edge of 256 VGPRs - as a
+    //  kernel of its own it compiled with four spilled registers, inside the pair kernel with none - and is not shipped)
+    return on && band_pair_enabled() && time_lstm_fuses_fc();
 }
 
 void launch_band_lstm(const float* xin, float* hout, const float* wpk, const void* wpk16, const float* bias,
-                      int N, int L, int IN, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb)
+                      int N, int L, int IN, int* range_flag, hipStream_t stream)
 {
     if (N <= 0 || L <= 0) return;
     dim3 grid((N + 15) / 16, 2), block(256);
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
         static const bool paired = [] { const char* e = getenv("BSRNN_BAND_GRID"); return !(e && !strcmp(e, "2d")); }();   // A/B: 2d = one direction after the other
         if (paired) grid = dim3((((N + 15) / 16 + 7) / 8) * 16);      // both directions of eight tiles per 16 consecutive workgroups
-        if (IN == 128 && fc16) {
-            hipLaunchKernelGGL((band_lstm_h2_kernel<128, false, true>), grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, range_flag,
-                               (unsigned long long*)nullptr, (const uint4*)fc16, fcb);
-            return;
-        }
         if (IN == 64)
             hipLaunchKernelGGL(band_lstm_h2_kernel<64>, grid, block, 0, stream, xin, hout, (const uint4*)wpk16, bias, N, L, range_flag, (unsigned long long*)nullptr);
         else

@@ -132,8 +132,14 @@ def test_dual_path_flows_agree_at_rounding_level(kind):
     differ only in the time kernel (bit-identical h and state by construction) agree to the same bound."""
     with tempfile.TemporaryDirectory() as d:
         _, part = run_child(kind, {}, d, "part")
+        _, unpaired = run_child(kind, {"BSRNN_BAND_PAIR": "0", "BSRNN_BAND_GRID": "2d"}, d, "unpaired")
         _, gemm = run_child(kind, {"BSRNN_BAND_FC": "gemm"}, d, "gemm")
         _, v2 = run_child(kind, {"BSRNN_BAND_FC": "gemm", "BSRNN_TIME_KERNEL": "v2"}, d, "v2")
+    # BSRNN_BAND_PAIR=0 is round 2's flow entirely (one launch per band layer on the 2-D grid, the fc as a GEMM launch): it must be the
+    # GEMM-fc flow bit for bit - with or without the pair launch the band layers do the same arithmetic on the same numbers
+    # (the pair launch with the fc shares against separate launches, bit for bit: tools/band_parts_check.hip)
+    for k in part:
+        assert np.array_equal(gemm[k], unpaired[k]), k
     for name, a, b in (("parts vs gemm fc", part, gemm), ("16-wave vs 8-wave time kernel", gemm, v2)):
         for k in a:
             rel = maxabs(a[k], b[k]) / np.abs(b[k]).max()

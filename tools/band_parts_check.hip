@@ -121,6 +121,62 @@ static int band(int N, int L, int runs)
     return (bad != 0) + (untouched != 0) + (unstable != 0);
 }
 
+// (3) both layers in one launch (band_pair_h2_kernel, partner workgroups hand the layer-0 planes over through L2) against layer 0 and
+//     layer 1 (with the shares) as two launches: bit for bit, every run
+static int pair(int N, int L, int runs)
+{
+    const size_t nrow = (size_t)N * L;
+    const size_t nw0 = (size_t)2 * 4 * 4 * 4 * 2 * 64 * 8, nw1 = (size_t)2 * 4 * 6 * 4 * 2 * 64 * 8, nfc = (size_t)4 * 4 * 2 * 64 * 8;
+    float *z, *hb0, *hb0b, *p_ref, *p_pair, *b0, *b1, *bfc; uint16_t *w0, *w1, *wfc; int* flags;
+    CK(hipMalloc(&z, nrow * 64 * 4)); CK(hipMalloc(&hb0, nrow * 128 * 4)); CK(hipMalloc(&hb0b, nrow * 128 * 4));
+    CK(hipMalloc(&p_ref, nrow * 128 * 4)); CK(hipMalloc(&p_pair, nrow * 128 * 4));
+    CK(hipMalloc(&w0, nw0 * 2)); CK(hipMalloc(&w1, nw1 * 2)); CK(hipMalloc(&wfc, nfc * 2));
+    CK(hipMalloc(&b0, 512 * 4)); CK(hipMalloc(&b1, 512 * 4)); CK(hipMalloc(&bfc, 64 * 4));
+    const size_t nfl = 2 * ((size_t)(N + 15) / 16) + 64;
+    CK(hipMalloc(&flags, nfl * 4)); CK(hipMemset(flags, 0, nfl * 4));
+    std::vector<float> hz(nrow * 64), hb(512), hbfc(64);
+    for (auto& v : hz) v = urand() * 2.f;
+    std::vector<uint16_t> hw0(nw0), hw1(nw1), hwfc(nfc);
+    for (auto& v : hw0) v = small_half();
+    for (auto& v : hw1) v = small_half();
+    for (auto& v : hwfc) v = small_half();
+    CK(hipMemcpy(z, hz.data(), hz.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(w0, hw0.data(), nw0 * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(w1, hw1.data(), nw1 * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(wfc, hwfc.data(), nfc * 2, hipMemcpyHostToDevice));
+    for (auto& v : hb) v = urand() * 0.5f;
+    CK(hipMemcpy(b0, hb.data(), 512 * 4, hipMemcpyHostToDevice));
+    for (auto& v : hb) v = urand() * 0.5f;
+    CK(hipMemcpy(b1, hb.data(), 512 * 4, hipMemcpyHostToDevice));
+    for (auto& v : hbfc) v = urand() * 0.5f;
+    CK(hipMemcpy(bfc, hbfc.data(), 64 * 4, hipMemcpyHostToDevice));
+    const dim3 g2((N + 15) / 16, 2), g1((((N + 15) / 16 + 7) / 8) * 16), block(256);
+    printf("== band block as one launch, N=%d sequences x L=%d positions (%d workgroups)\n", N, L, g1.x);
+    hipLaunchKernelGGL((band_lstm_h2_kernel<64, false, false>), g2, block, 0, 0, z, hb0, (const uint4*)w0, b0, N, L, (int*)nullptr, (unsigned long long*)nullptr, (const uint4*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL((band_lstm_h2_kernel<128, false, true>), g2, block, 0, 0, (const float*)hb0, p_ref, (const uint4*)w1, b1, N, L, (int*)nullptr, (unsigned long long*)nullptr, (const uint4*)wfc, bfc);
+    CK(hipDeviceSynchronize());
+    std::vector<uint32_t> ref(nrow * 128), cur(nrow * 128);
+    CK(hipMemcpy(ref.data(), p_ref, ref.size() * 4, hipMemcpyDeviceToHost));
+    int* flag; CK(hipMalloc(&flag, 4)); CK(hipMemset(flag, 0, 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f; size_t total = 0;
+    for (int r = 0; r < runs; ++r) {
+        CK(hipMemset(p_pair, 0xff, nrow * 128 * 4)); CK(hipMemset(hb0b, 0xff, nrow * 128 * 4));
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((band_pair_h2_kernel<true>), g1, block, 0, 0, (const float*)z, hb0b, p_pair, (const uint4*)w0, b0, (const uint4*)w1, b1, N, L, flag,
+                           (const uint4*)wfc, bfc, flags);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms * 1e3f);
+        CK(hipMemcpy(cur.data(), p_pair, cur.size() * 4, hipMemcpyDeviceToHost));
+        size_t d = 0; for (size_t i = 0; i < cur.size(); ++i) d += cur[i] != ref[i];
+        total += d;
+        if (d) printf("   run %d: %zu words differ from the two launches\n", r, d);
+    }
+    int hf = 0; CK(hipMemcpy(&hf, flag, 4, hipMemcpyDeviceToHost));
+    printf("   pair launch %.1f us; words differing from layer 0 + layer 1 as two launches over %d runs: %zu; flag %d\n", best, runs, total, hf);
+    hipFree(z); hipFree(hb0); hipFree(hb0b); hipFree(p_ref); hipFree(p_pair); hipFree(w0); hipFree(w1); hipFree(wfc); hipFree(b0); hipFree(b1); hipFree(bfc); hipFree(flags); hipFree(flag);
+    return total != 0 || hf != 0;
+}
+
 static int timek(int R, int T, int K, int runs)
 {
     const int N = R * K;
@@ -180,6 +236,10 @@ int main(int argc, char** argv)
     fails += band(8064, 12, 4);
     fails += band(32768, 12, 6);
     fails += band(700, 42, 3);
+    fails += pair(37, 12, 3);
+    fails += pair(8064, 12, 6);
+    fails += pair(32768, 12, 6);
+    fails += pair(700, 42, 3);
     fails += timek(2, 5, 12, 3);
     fails += timek(3, 9, 5, 3);
     fails += timek(64, 126, 12, 6);
