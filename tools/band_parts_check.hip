@@ -1,4 +1,5 @@
-// Validation only: the "fc in parts" flow of the dual path (lstm.hip): band_lstm_h2_kernel<128, ., PART> writes the two directions'
+// Validation only: the "fc in parts" flow of the dual path (lstm.hip): the second band layer (here also as a kernel of its own, which the
+// library does not ship: band_lstm_h2_kernel<128, ., PART>) writes the two directions'
 // shares of the block's fc, time_lstm_h2w_kernel<FUSE, ., PART> adds them and the residual while staging.
 //   (1) band layer 1 with PART against the same layer without it + fc(h) evaluated in double; run-to-run bit stability
 //   (2) time kernel with PART on (z, part) against the kernel without PART on the pre-added rows (z + pf) + pb: bit-identical;

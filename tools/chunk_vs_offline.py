@@ -1,3 +1,5 @@
+"""Diagnostic: offline forward run to run, and two chunks of 256 frames with state carry against offline, bit for bit, at R = 2, 8, 64
+(how the missing barrier of the band kernels' first step was found: NOTEBOOK.md R3.9)."""
 import numpy as np, torch, sys
 import os
 sys_path = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
