@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void band_pair_h2_kernel(const float* __res
                                                               const uint4* __restrict__ w1, const float* __restrict__ b1,
                                                               int N, int L, int* __restrict__ range_flag,
                                                               const uint4* __restrict__ wfc, const float* __restrict__ bfc,
-                                                              int* flags)
+                                                              int* flags, int sabotage)
 {
     constexpr int B0 = BandLds<HID, false>::BYTES, B1 = BandLds<2 * HID, PART>::BYTES;
     __shared__ __attribute__((aligned(16))) char lds[B0 > B1 ? B0 : B1];
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void band_pair_h2_kernel(const float* __res
         const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;      // HW_REG_XCC_ID[3:0]
         // the pair's two flags count the launches that covered this tile, in lockstep: mine + 1 is this launch's number for both
         const int epoch = ((__hip_atomic_load(&flags[2 * tile + dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 4) + 1) & 0x7ffffff;
-        __hip_atomic_store(&flags[2 * tile + dir], (epoch << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&flags[2 * tile + dir], (epoch << 4) | (sabotage ? (xcc ^ 8) : xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0, v;
         while (((v = __hip_atomic_load(&flags[2 * tile + (dir ^ 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) != epoch) {
             __builtin_amdgcn_s_sleep(8);
@@ -584,12 +584,15 @@ void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16
 {
     if (N <= 0 || L <= 0) return;
     const dim3 grid((((N + 15) / 16 + 7) / 8) * 16), block(256);
+    // test hook (tests/test_gpu_edges.py): BSRNN_BAND_PAIR=mismatch makes every workgroup publish a wrong XCC id, as if its partner sat on
+    // another XCD - the launch reports it (guard value 4) and the context falls back to one launch per layer
+    static const int sabotage = [] { const char* e = getenv("BSRNN_BAND_PAIR"); return (e && !strcmp(e, "mismatch")) ? 1 : 0; }();
     if (fc16)
         hipLaunchKernelGGL((band_pair_h2_kernel<true>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
-                           range_flag, (const uint4*)fc16, fcb, flags);
+                           range_flag, (const uint4*)fc16, fcb, flags, sabotage);
     else
         hipLaunchKernelGGL((band_pair_h2_kernel<false>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
-                           range_flag, (const uint4*)nullptr, (const float*)nullptr, flags);
+                           range_flag, (const uint4*)nullptr, (const float*)nullptr, flags, sabotage);
 }
 
 // BSRNN_BAND_FC = part (default: the second band layer writes the two directions' shares of the block's fc, the time-axis launch adds

@@ -133,6 +133,7 @@ def test_dual_path_flows_agree_at_rounding_level(kind):
     with tempfile.TemporaryDirectory() as d:
         _, part = run_child(kind, {}, d, "part")
         _, unpaired = run_child(kind, {"BSRNN_BAND_PAIR": "0", "BSRNN_BAND_GRID": "2d"}, d, "unpaired")
+        _, fallback = run_child(kind, {"BSRNN_BAND_PAIR": "mismatch"}, d, "fallback")
         _, gemm = run_child(kind, {"BSRNN_BAND_FC": "gemm"}, d, "gemm")
         _, v2 = run_child(kind, {"BSRNN_BAND_FC": "gemm", "BSRNN_TIME_KERNEL": "v2"}, d, "v2")
     # BSRNN_BAND_PAIR=0 is round 2's flow entirely (one launch per band layer on the 2-D grid, the fc as a GEMM launch): it must be the
@@ -140,6 +141,10 @@ def test_dual_path_flows_agree_at_rounding_level(kind):
     # (the pair launch with the fc shares against separate launches, bit for bit: tools/band_parts_check.hip)
     for k in part:
         assert np.array_equal(gemm[k], unpaired[k]), k
+    # BSRNN_BAND_PAIR=mismatch (test hook): every workgroup of the pair launch finds its partner "on another XCD"; the first call notices
+    # (guard value 4), runs again with one launch per layer and the context stays on that flow - same numbers as BSRNN_BAND_PAIR=0, rc 0
+    for k in part:
+        assert np.array_equal(fallback[k], unpaired[k]), k
     for name, a, b in (("parts vs gemm fc", part, gemm), ("16-wave vs 8-wave time kernel", gemm, v2)):
         for k in a:
             rel = maxabs(a[k], b[k]) / np.abs(b[k]).max()

@@ -164,7 +164,7 @@ static int pair(int N, int L, int runs)
         CK(hipMemset(p_pair, 0xff, nrow * 128 * 4)); CK(hipMemset(hb0b, 0xff, nrow * 128 * 4));
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL((band_pair_h2_kernel<true>), g1, block, 0, 0, (const float*)z, hb0b, p_pair, (const uint4*)w0, b0, (const uint4*)w1, b1, N, L, flag,
-                           (const uint4*)wfc, bfc, flags);
+                           (const uint4*)wfc, bfc, flags, 0);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms * 1e3f);
         CK(hipMemcpy(cur.data(), p_pair, cur.size() * 4, hipMemcpyDeviceToHost));
