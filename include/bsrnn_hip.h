@@ -39,6 +39,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define BSRNN_ABI_VERSION 2      /* 2: range policy (bsrnn_set_range_policy), training entry points, bsrnn_forward_chunk refuses aliased state */
 
@@ -292,6 +296,9 @@ int  bsrnn_copy_h2d(bsrnn_ctx* ctx, void* dst_dev, const void* src_host, int64_t
 int  bsrnn_copy_d2h(bsrnn_ctx* ctx, void* dst_host, const void* src_dev, int64_t nbytes);
 int  bsrnn_sync(bsrnn_ctx* ctx, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

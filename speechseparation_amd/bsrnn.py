@@ -92,6 +92,7 @@ class BSRNN(nn.Module):
         self._ctx_device = None
         self._pushed_fingerprint = None
         self._plist = None                  # cached parameter tensors (the module tree is fixed after construction)
+        self._pident = ()                   # their (id, data_ptr) pairs when the list was built
         self._epoch = 0                     # bumped by everything that may rebind parameter storage (_apply, load_state_dict)
         self._range_policy = _native.RANGE_EXACT
 
@@ -105,11 +106,27 @@ class BSRNN(nn.Module):
 
     def _fingerprint(self):
         """Cheap identity of the current weights: every in-place edit of a parameter bumps its tensor's `_version`; `.to()` /
-        `.cuda()` / `.float()` (all through `_apply`) and `load_state_dict` bump `_epoch`.  One attribute read per parameter
-        (a walk of `self.parameters()` with `data_ptr()` cost more than the GPU work of a streaming step it guarded)."""
+        `.cuda()` / `.float()` (all through `_apply`) and `load_state_dict` bump `_epoch`; rebinding a parameter's storage
+        (`p.data = t`, `module.weight = Parameter(...)`, `swap_tensors`) changes the (id, data_ptr) pairs taken when the
+        parameter list is (re)built.  One attribute read per parameter per check."""
         if self._plist is None:
             self._plist = list(self.parameters())
-        return (self._epoch,) + tuple(p._version for p in self._plist)
+            self._pident = tuple((id(p), p.data_ptr()) for p in self._plist)
+        return (self._epoch, self._pident) + tuple(p._version for p in self._plist)
+
+    def _weights_touched(self, k, n=8):
+        """Slice k of n of the cached parameter list: has any of them been edited in place or had its storage rebound since
+        the last upload?  (The streaming wrapper calls this every step with a rotating k: an optimizer step or any other
+        edit of ALL parameters is seen at the very next chunk, an edit of ONE tensor within n chunks, for ~3 us per step.)"""
+        fp = self._pushed_fingerprint
+        if fp is None or self._plist is None:
+            return True
+        pl, ident, vers = self._plist, fp[1], fp[2:]
+        for i in range(k % n, len(pl), n):
+            p = pl[i]
+            if p._version != vers[i] or p.data_ptr() != ident[i][1]:
+                return True
+        return False
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -359,9 +376,13 @@ class StreamingSeparator:
         """chunk [C, 1024] float32 (cuda or cpu) -> same-shaped output on the same device."""
         if tuple(chunk.shape) != (self.C, _spec.HOP):
             raise ValueError("expected chunk [%d, 1024], got %s" % (self.C, tuple(chunk.shape)))
-        # the weights of a running stream are looked at every 32nd step only (a parameter edited in place takes effect within 32
-        # chunks; model.refresh_weights() + the next step forces it): the check is host time on a ~0.2 ms step
-        if self._steps % 32 == 0 or self.model._pushed_fingerprint is None:
+        # The reference's forward_recurrent always sees the current parameters (bsrnn.py:445).  Here the weights live packed on the
+        # device, so a running stream looks at the model every step, cheaply: a rotating eighth of the parameters' version counters
+        # and storage pointers per step (an optimizer step or load_state_dict is seen at the next chunk, an in-place edit or
+        # rebinding of a single tensor within 8 chunks), and the whole module tree again every 32nd step (a parameter OBJECT
+        # swapped into a submodule).  model.refresh_weights() forces it at once.
+        if self._steps % 32 == 0 or self.model._weights_touched(self._steps):
+            self.model._plist = None            # (re-read the parameter objects and their storage pointers)
             with torch.cuda.device(self.device):
                 self.model._context(self.device)
         self._steps += 1

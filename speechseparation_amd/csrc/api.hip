@@ -105,6 +105,8 @@ struct bsrnn_ctx {
     float* d_tables = nullptr;
     float* d_train_ws = nullptr;       // grow-only scratch of the training entry points (stream-ordered reuse: one call at a time)
     size_t train_ws_floats = 0;
+    std::vector<float*> train_ws_retired;   // outgrown scratch buffers: a captured training graph (train.GraphedTrainStep) may still point at
+                                            // them, so they live until the context goes (growth is geometric: at most ~4x the final size in all)
     int* d_colmap = nullptr;
     FftTables tb;
 
@@ -420,7 +422,7 @@ struct Part {
     const float* wave; float* wave_out; int64_t n;       // only for the fused sandwich
 };
 
-Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s)
+Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s, int j = 0)
 {
     Part p;
     memset(&p, 0, sizeof p);
@@ -430,7 +432,9 @@ Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s)
     p.A1 = c->A1 + m0 * c->LDA; p.A2 = c->A2 + m0 * c->LDA; p.P = c->P + m0 * c->LDP;
     p.Z0 = c->Z0 + m0 * KH; p.Z1 = c->Z1 + m0 * KH; p.H1 = c->H1 + m0 * KH;
     p.HB0 = c->HB0 + m0 * KH * 2; p.HB1 = c->HB1 + m0 * KH * 2;
-    p.band_flags = c->band_flags + 2 * (m0 / 16) + 2 * (row0 ? 1 + row0 % MAX_PARTS : 0);      // (row blocks never share a flag pair)
+    // Row block j starts j pairs behind its first tile's natural place: block j - 1 ends at most at floor(m0 / 16) + 1 + (j - 1), so the
+    // pair ranges of concurrent blocks are disjoint for any row split (odd R, 3 or 4 blocks included; checked in bsrnn_separate)
+    p.band_flags = c->band_flags + 2 * (m0 / 16 + j);
     return p;
 }
 
@@ -578,6 +582,7 @@ int check_range(bsrnn_ctx* c)
         if (v == 3) return fail(BSRNN_EHIP, "an earlier time-axis LSTM launch gave up waiting on its own workgroup-local counters (internal error)");
         if (v == 4) {
             c->band_pair_off = true;
+            ++c->gen;                                 // captured streaming graphs contain the pair launch: re-capture with one launch per layer
             return fail(BSRNN_EHIP, "an earlier band-axis launch (both layers in one launch, range policy 'deferred') did not find its partner workgroups on the "
                                     "same XCD in time; its results are invalid - repeat the call (the context now runs one launch per layer)");
         }
@@ -601,6 +606,7 @@ int finish_call(bsrnn_ctx* c, hipStream_t s, F&& rerun)
     if (v == 3) return fail(BSRNN_EHIP, "the time-axis LSTM launch gave up waiting on its own workgroup-local counters (internal error)");
     if (v == 4) {                                 // the band-pair launch's partners did not meet (placement / dispatch order not as assumed): the
         c->band_pair_off = true;                  // same call again with one launch per layer, same arithmetic; pairing stays off for this context
+        ++c->gen;                                 // (a streaming graph captured with the pair launch is re-captured by the re-run below)
         if (int rc4 = rerun()) return rc4;
         HIP_TRY(hipStreamSynchronize(s));
         const int v4 = *(volatile int*)c->h_range;
@@ -772,6 +778,7 @@ static void destroy_now(bsrnn_ctx* c)
         for (int ch = 0; ch < 2; ++ch) (void)hipFree(kv.second.d[ch]);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_train_ws) (void)hipFree(c->d_train_ws);
+    for (float* p : c->train_ws_retired) (void)hipFree(p);
     if (c->d_colmap) (void)hipFree(c->d_colmap);
     if (c->h_range) (void)hipHostFree(c->h_range);
     delete c;
@@ -1410,11 +1417,14 @@ int bsrnn_dual_path(bsrnn_ctx* c, const float* z, float* z_out, const float* sta
 static float* train_scratch(bsrnn_ctx* c, size_t floats)
 {
     if (floats <= c->train_ws_floats) return c->d_train_ws;
-    (void)hipDeviceSynchronize();
-    if (c->d_train_ws) (void)hipFree(c->d_train_ws);
-    c->d_train_ws = nullptr; c->train_ws_floats = 0;
+    // Grow: the old buffer is RETIRED, not freed.  Kernel nodes of a captured training iteration hold its address; a later, larger
+    // clip (its eager warm-up or an eager fall-back clip) must not turn those graphs into writers of freed memory.  A retired
+    // buffer stays valid scratch for the graphs that know it (they are replayed one at a time, in stream order, like every call).
+    float* fresh = nullptr;
     const size_t want = floats + floats / 4;
-    if (hipMalloc((void**)&c->d_train_ws, want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); c->d_train_ws = nullptr; return nullptr; }
+    if (hipMalloc((void**)&fresh, want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (c->d_train_ws) c->train_ws_retired.push_back(c->d_train_ws);
+    c->d_train_ws = fresh;
     c->train_ws_floats = want;
     return c->d_train_ws;
 }
@@ -1692,7 +1702,9 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
     }
     for (int j = 0; j < parts; ++j) {
         const int r0 = (int)((int64_t)R * j / parts), r1 = (int)((int64_t)R * (j + 1) / parts);
-        pt[j] = make_part(c, r0, r1 - r0, T, parts > 1 ? c->aux[j] : s);
+        pt[j] = make_part(c, r0, r1 - r0, T, parts > 1 ? c->aux[j] : s, j);
+        if (j && pt[j].band_flags < pt[j - 1].band_flags + 2 * (((size_t)pt[j - 1].C * T + 15) / 16))
+            return fail(BSRNN_ESTATE, "row blocks %d and %d would share a hand-over flag pair (internal error)", j - 1, j);
         pt[j].wave = wave + (size_t)r0 * n; pt[j].n = n;
         pt[j].wave_out = wave_out + (size_t)r0 * out_len;
     }
