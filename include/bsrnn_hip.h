@@ -104,6 +104,17 @@ int  bsrnn_get_range_policy(const bsrnn_ctx* ctx);
  * exact-fp32 mode, BSRNN_MLP=layers (A/B), or a band table with a band too wide for the fused kernel's LDS image
  * (more than 768 columns).  Same arithmetic, bit-identical results either way. */
 int  bsrnn_mlp_fused(const bsrnn_ctx* ctx);
+/* How this context runs the dual path of large calls (bsrnn.py:352-356, the four recurrent blocks): 1 = overlapped - the second band
+ * block is launched beside the first (causal) time-axis launch and the mask MLPs beside the second, on an auxiliary stream of the
+ * context, each workgroup waiting for the frames of its own rows (results are bit-identical to 0); 0 = one launch after the other
+ * (environment BSRNN_OVERLAP=0); 2 = switched off for good after a consumer's bounded wait expired once (that call was run again launch
+ * after launch before it returned; under the 'deferred' range policy it is reported by the next call instead).  Calls of fewer than
+ * 32 frames or 8 rows x 12 bands never overlap.  Measurement / test support. */
+int  bsrnn_overlap_state(const bsrnn_ctx* ctx);
+/* Measurement / debugging: copy the first `nfloats` floats of one of the context's internal activation buffers of the LAST call to the
+ * host (synchronises the device).  which: 0 = Z0, 1 = Z1 (the dual-path tensor's two buffers, [rows*frames][K][64]), 2 = HB1 (the
+ * band blocks' fc shares, [rows*frames][K][2][64]), 3 = P, 4 = Yf (band-padded rows of LDP floats). */
+int  bsrnn_debug_peek(bsrnn_ctx* ctx, int32_t which, float* host_out, int64_t nfloats);
 
 /* ---- parameters ---------------------------------------------------------------------
  * Replaces `load_state_dict` (infer.py:19, infer-streaming.py:46): parameters are named

@@ -176,6 +176,12 @@ class BSRNN(nn.Module):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         return "fused" if _lib.bsrnn_mlp_fused(self._context(dev)) == 1 else "layers"
 
+    def overlap_state(self, device=None):
+        """How this model's context runs the dual path of large calls: 1 overlapped (default), 0 launch after launch (BSRNN_OVERLAP=0),
+        2 switched off after a consumer's wait expired (include/bsrnn_hip.h, bsrnn_overlap_state)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return _lib.bsrnn_overlap_state(self._context(dev))
+
     def sync(self, device=None):
         """Wait for this model's work on the current stream of `device`; raises if a call made under the 'deferred' range
         policy left the fp16x2 range (bsrnn_sync)."""

@@ -127,6 +127,20 @@ struct bsrnn_ctx {
     int64_t acc_n[NSTAGE];
     hipStream_t last_stream = nullptr;
 
+    // Overlapped dual path (run_overlapped below; kernels.h, OvlProducer / OvlConsumer): the second band block runs beside the first
+    // time-axis launch and the mask chain beside the second, on the context's first auxiliary stream.
+    bool overlap_env = true;        // BSRNN_OVERLAP=0: one launch after the other on the caller's stream (A/B; bit-identical results)
+    int overlap_mode = 3;           // bit 0: the second band block beside the first time-axis launch; bit 1: the mask chain beside the second
+                                    // (BSRNN_OVERLAP=band | mask | 1 = both); bit 2 (BSRNN_OVERLAP=pub, measurement): the publishing / waiting
+                                    // launches one after the other on the caller's stream
+    int overlap_sabotage = 0;       // BSRNN_OVERLAP=timeout (test hook): the producers publish nothing, the consumers give up after ~2 ms
+    bool overlap_off = false;       // a consumer's wait expired once (range flag value 5): this context runs launch after launch from then on
+    int* d_ovl = nullptr;           // [2 time blocks][OVL_HEAD ints: resident counter | progress word per time-axis workgroup]
+    int ovl_stride = 0;             // ints per block
+    struct OvlTable { int2* mask_tasks; int n_mask; int* band_order; int n_ord; };
+    std::map<std::pair<int, int>, OvlTable> ovl_tables;       // per (rows C, frames T): consumer dispatch orders by readiness
+    hipEvent_t ev_ovl_fork = nullptr, ev_ovl_join = nullptr;
+
     // concurrent row blocks of one call (bsrnn_separate)
     // BSRNN_PARTS / BSRNN_PART_LAG.  0 = automatic: two row blocks on two streams from 128 rows on (blocks of >= 64 rows), the
     // second one stage behind the first: one block's matrix work fills the other's latency-bound time-axis LSTM (192 of 256
@@ -141,6 +155,7 @@ struct bsrnn_ctx {
 };
 
 constexpr int MAX_PARTS = 4;
+constexpr int OVL_HEAD = 16;          // ints in front of a block's progress words (the resident counter on a line of its own)
 
 struct bsrnn_stream {
     bsrnn_ctx* ctx;
@@ -420,6 +435,8 @@ struct Part {
     const float* state_in; float* state_out;             // [4][2][C_total*K][64] slabs already offset to this part's first row
     size_t state_slab;                                   // floats between the two Time blocks' slabs (uses C_total)
     const float* wave; float* wave_out; int64_t n;       // only for the fused sandwich
+    const bsrnn_ctx::OvlTable* ovl;                      // non-null: the overlapped flow (run_overlapped) - producers publish, consumers wait
+    int ovl_mode;                                        // ... which of the two hand-overs (bsrnn_ctx::overlap_mode)
 };
 
 Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s, int j = 0)
@@ -487,8 +504,12 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         const bool parts = ctx_parts(c);
         const float* zi = parts && blk ? p.Z1 : p.Z0;
         if (ctx_pair(c)) {                        // both layers in one launch (A/B: BSRNN_BAND_PAIR=0)
+            OvlConsumer oc = {nullptr, 0, 0, nullptr};
+            const bool cons = p.ovl && blk && (p.ovl_mode & 1);
+            if (cons)                             // beside the first time-axis launch: tiles in the order their frames leave it
+                oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 4096 : OVL_SPIN_LIMIT, p.ovl->band_order};
             launch_band_pair(zi, p.HB0, p.HB1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1], M, K, c->d_range, s,
-                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags);
+                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr);
             break;
         }
         launch_band_lstm(zi, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
@@ -508,10 +529,13 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         // fp16x2 mode: the launch also computes the block's fc + residual (out = fc(h1) + Z1 -> Z0); otherwise it writes h1
         const bool fused = time_lstm_fuses_fc();
         if (ctx_parts(c) && !band_block_is_small(M, K)) {
+            OvlProducer op = {nullptr, nullptr};
+            const bool prod = p.ovl && (p.ovl_mode & (blk ? 2 : 1));
+            if (prod) op = OvlProducer{c->d_ovl + blk * c->ovl_stride, c->overlap_sabotage ? nullptr : c->d_ovl + blk * c->ovl_stride + OVL_HEAD};
             launch_time_lstm(blk ? p.Z1 : p.Z0, blk ? p.Z0 : p.Z1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
                              p.state_in ? p.state_in + blk * p.state_slab : nullptr,
                              p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, c->d_range, s,
-                             c->timeFc16[blk], c->timeFcB[blk], p.HB1);
+                             c->timeFc16[blk], c->timeFcB[blk], p.HB1, prod ? &op : nullptr);
             break;
         }
         launch_time_lstm(p.Z1, fused ? p.Z0 : p.H1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
@@ -538,6 +562,11 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
             g.desc = c->d_chain[CHAIN_MASK]; g.tasks = tt.d[CHAIN_MASK]; g.n_tasks = tt.n[CHAIN_MASK];
             g.M = M; g.Xin = p.Z0; g.ldx = KH; g.P = p.P; g.ldp = c->LDP; g.Xmul = p.Xf; g.ldm = c->LDP;
             g.Y = p.Yf; g.ldy = c->LDP; g.tap = p.tap; g.ldt = c->LDP; g.range_flag = c->d_range;
+            if (p.ovl && (p.ovl_mode & 2)) {      // beside the second time-axis launch: the earliest-ready heavy workgroups first
+                g.tasks = p.ovl->mask_tasks; g.n_tasks = p.ovl->n_mask;
+                g.ovl_prog = c->d_ovl + c->ovl_stride + OVL_HEAD; g.ovl_T = p.T; g.ovl_K = K;
+                g.ovl_spin = c->overlap_sabotage ? 4096 : OVL_SPIN_LIMIT;
+            }
             launch_mlp_chain(g, CHAIN_MASK, s);
             break;
         }
@@ -557,6 +586,135 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
     }
 }
 
+// ---- overlapped dual path ------------------------------------------------------------------------------------------------------
+// Whether a call of C rows x T frames runs overlapped: the fp16x2 parts flow with fused chains (the launches that know how to publish /
+// wait), a time-axis launch that leaves CUs free (<= 224 of 256 workgroups) and enough frames for a head start to exist.
+static bool overlap_wanted(const bsrnn_ctx* c, int C, int T)
+{
+    if (!c->overlap_env || c->overlap_off || !ctx_parts(c) || !c->fused || force_f32() || gemm_mode() == GEMM_F32) return false;
+    const int nwg = (C * c->K + 3) / 4;
+    return !band_block_is_small(C * T, c->K) && nwg >= 32 && nwg <= 224 && T >= 32 && C * T > GEMV_MAX_FRAME_ROWS;
+}
+static void free_ovl_tables(bsrnn_ctx* c)
+{
+    for (auto& kv : c->ovl_tables) { (void)hipFree(kv.second.mask_tasks); (void)hipFree(kv.second.band_order); }
+    c->ovl_tables.clear();
+}
+// Progress words and the consumers' dispatch orders for a call of C rows x T frames (made outside any capture, like the task tables).
+int ensure_ovl(bsrnn_ctx* c, int C, int T)
+{
+    if (!overlap_wanted(c, C, T)) return 0;
+    int rc = ensure_streams(c, 1);
+    if (rc) return rc;
+    if (!c->ev_ovl_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_fork, hipEventDisableTiming));
+    if (!c->ev_ovl_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_join, hipEventDisableTiming));
+    const int M = C * T, K = c->K, nwg = (C * K + 3) / 4;
+    const int stride = OVL_HEAD + ((nwg + 15) & ~15);
+    if (stride > c->ovl_stride) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->d_ovl) { HIP_TRY(hipFree(c->d_ovl)); c->d_ovl = nullptr; }
+        HIP_TRY(hipMalloc((void**)&c->d_ovl, (size_t)2 * stride * sizeof(int)));
+        HIP_TRY(hipMemset(c->d_ovl, 0, (size_t)2 * stride * sizeof(int)));
+        c->ovl_stride = stride;
+        ++c->gen;
+    }
+    const auto key = std::make_pair(C, T);
+    if (c->ovl_tables.find(key) != c->ovl_tables.end()) return 0;
+    if (c->ovl_tables.size() >= 16) { HIP_TRY(hipDeviceSynchronize()); free_ovl_tables(c); ++c->gen; }
+    // band block: tiles of 16 frame rows m = row * T + frame, sorted by the last frame the tile needs (a tile that straddles two batch
+    // rows needs the first one's last frame); padded with -1 to the launch's whole groups of eight tiles
+    const int tiles = (M + 15) / 16, n_ord = ((tiles + 7) / 8) * 8;
+    std::vector<int> order(tiles), ready(tiles);
+    for (int t = 0; t < tiles; ++t) {
+        const int m0 = 16 * t, m1 = std::min(M - 1, m0 + 15);
+        order[t] = t;
+        ready[t] = m0 / T != m1 / T ? T - 1 : m1 % T;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ready[a] < ready[b]; });
+    order.resize(n_ord, -1);
+    // mask chain: its task table (longest workgroups first) with the workgroups that can START while the time-axis launch still runs
+    // in front: as many as that launch leaves CUs free (each runs longer than the rest of it), the earliest-ready of the heavy classes
+    // (<= 80 rows per workgroup: the widest bands, which also end the launch when they start late)
+    std::vector<int2> tasks;
+    build_chain_tasks(c, CHAIN_MASK, M, tasks);
+    const auto& ds = c->h_chain[CHAIN_MASK];
+    std::vector<int> cand;
+    auto task_ready = [&](const int2& t) {
+        const int m1 = std::min(M - 1, t.y + chain_rows(ds[t.x]) - 1);
+        return t.y / T != m1 / T ? T - 1 : m1 % T;
+    };
+    for (int i = 0; i < (int)tasks.size(); ++i)
+        if (!ds[tasks[i].x].constant && chain_rows(ds[tasks[i].x]) <= 80 && task_ready(tasks[i]) < T - 1) cand.push_back(i);
+    std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return task_ready(tasks[a]) < task_ready(tasks[b]); });
+    const int n_early = std::min((int)cand.size(), std::max(0, 256 - nwg));
+    std::vector<char> early(tasks.size(), 0);
+    std::vector<int2> mt;
+    for (int i = 0; i < n_early; ++i) { mt.push_back(tasks[cand[i]]); early[cand[i]] = 1; }
+    for (int i = 0; i < (int)tasks.size(); ++i)
+        if (!early[i]) mt.push_back(tasks[i]);
+    bsrnn_ctx::OvlTable tb;
+    tb.mask_tasks = nullptr; tb.band_order = nullptr; tb.n_mask = (int)mt.size(); tb.n_ord = n_ord;
+    hipError_t e = hipMalloc((void**)&tb.mask_tasks, (mt.size() + 1) * sizeof(int2));
+    if (e == hipSuccess) e = hipMemcpy(tb.mask_tasks, mt.data(), mt.size() * sizeof(int2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&tb.band_order, (size_t)n_ord * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(tb.band_order, order.data(), (size_t)n_ord * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (tb.mask_tasks) (void)hipFree(tb.mask_tasks);
+        if (tb.band_order) (void)hipFree(tb.band_order);
+        return fail(BSRNN_EHIP, "overlap tables: %s", hipGetErrorString(e));
+    }
+    c->ovl_tables.emplace(key, tb);
+    return 0;
+}
+
+// The stages of one part with the dual path overlapped (kernels.h): caller's stream A, the context's auxiliary stream B.
+//   A: [STFT] BandSplit, zero the progress words, band block 0, TIME 0 ............ gate 1, MASK chain (waits per workgroup), [iSTFT]
+//   B:                                        (fork) gate 0, BAND block 1 (waits per tile), TIME 1 ......................... (join)
+// gate b = one wave that leaves when every workgroup of time launch b is resident: no consumer workgroup is dispatched before that, so a
+// waiting consumer never holds a CU a producer needs; producers wait for nobody.  Same kernels, same arithmetic, other dispatch order:
+// bit-identical to the serial flow (tests/test_gpu_overlap.py).
+void run_overlapped(bsrnn_ctx* c, Part p, const bsrnn_ctx::OvlTable* tb, int first, int last)
+{
+    hipStream_t A = p.s, B = c->aux[0];
+    p.ovl = tb;
+    p.ovl_mode = c->overlap_mode;
+    const bool band = p.ovl_mode & 1, mask = p.ovl_mode & 2, serial = p.ovl_mode & 4;
+    Part pb = p;
+    if (!serial) pb.s = B;
+    const int nwg = (p.C * c->K + 3) / 4, limit = OVL_SPIN_LIMIT;
+    for (int st = first; st <= MS_BANDSPLIT; ++st) run_stage(c, p, st);
+    (void)hipMemsetAsync(c->d_ovl, 0, (size_t)2 * c->ovl_stride * sizeof(int), A);
+    run_stage(c, p, MS_BAND0);
+    auto fork = [&]() { if (!serial) { (void)hipEventRecord(c->ev_ovl_fork, A); (void)hipStreamWaitEvent(B, c->ev_ovl_fork, 0); } };
+    auto join = [&]() { if (!serial) { (void)hipEventRecord(c->ev_ovl_join, B); (void)hipStreamWaitEvent(A, c->ev_ovl_join, 0); } };
+    if (band) {
+        fork();
+        run_stage(c, p, MS_TIME0);
+        launch_ovl_gate(c->d_ovl, nwg, c->d_range, limit, pb.s);
+        run_stage(c, pb, MS_BAND1);
+        run_stage(c, pb, MS_TIME1);
+        if (mask) launch_ovl_gate(c->d_ovl + c->ovl_stride, nwg, c->d_range, limit, A);
+        else join();
+        run_stage(c, p, MS_MASK);
+        if (mask) join();
+    } else {                                      // the mask chain alone beside the second time-axis launch
+        run_stage(c, p, MS_TIME0);
+        run_stage(c, p, MS_BAND1);
+        fork();
+        run_stage(c, pb, MS_TIME1);
+        launch_ovl_gate(c->d_ovl + c->ovl_stride, nwg, c->d_range, limit, A);
+        run_stage(c, p, MS_MASK);
+        join();
+    }
+    for (int st = MS_MASK + 1; st <= last; ++st) run_stage(c, p, st);
+}
+static const bsrnn_ctx::OvlTable* ovl_table(const bsrnn_ctx* c, int C, int T)
+{
+    if (!overlap_wanted(c, C, T) || !c->d_ovl) return nullptr;
+    auto it = c->ovl_tables.find(std::make_pair(C, T));
+    return it == c->ovl_tables.end() ? nullptr : &it->second;
+}
+
 // The model proper for a single part on one stream.
 int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T,
               const float* state_in, float* state_out, hipStream_t s)
@@ -567,6 +725,9 @@ int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T
     p.Xf = Xf; p.Yf = Yf; p.tap = tap;
     p.state_in = state_in; p.state_out = state_out;
     p.state_slab = (size_t)2 * 2 * C * c->K * HID;     // one Time block's (h,c) x 2 layers
+    const bsrnn_ctx::OvlTable* tb = c->small_rows ? nullptr : ovl_table(c, C, T);
+    if (tb) run_overlapped(c, p, tb, MS_BANDSPLIT, MS_MASK);
+    else
     for (int st = MS_BANDSPLIT; st <= MS_MASK; ++st) run_stage(c, p, st);
     c->small_rows = false;
     if (c->stage_error) { c->stage_error = false; return fail(BSRNN_ESTATE, "no task table for %d frame rows (internal error)", C * T); }
@@ -586,6 +747,12 @@ int check_range(bsrnn_ctx* c)
             return fail(BSRNN_EHIP, "an earlier band-axis launch (both layers in one launch, range policy 'deferred') did not find its partner workgroups on the "
                                     "same XCD in time; its results are invalid - repeat the call (the context now runs one launch per layer)");
         }
+        if (v == 5) {
+            c->overlap_off = true;
+            ++c->gen;
+            return fail(BSRNN_EHIP, "an earlier call (range policy 'deferred') ran its dual path overlapped and a consumer workgroup gave up waiting for the "
+                                    "time-axis launch beside it; its results are invalid - repeat the call (the context now runs launch after launch)");
+        }
         return fail(BSRNN_ERANGE, "an earlier call (range policy 'deferred') fed the fp16x2 matrix path an activation beyond +-65504; its "
                                   "results are invalid - repeat it under the default policy, rescale the input or set BSRNN_GEMM=f32 BSRNN_LSTM=f32");
     }
@@ -604,16 +771,20 @@ int finish_call(bsrnn_ctx* c, hipStream_t s, F&& rerun)
     if (!v) return 0;
     *(volatile int*)c->h_range = 0;
     if (v == 3) return fail(BSRNN_EHIP, "the time-axis LSTM launch gave up waiting on its own workgroup-local counters (internal error)");
-    if (v == 4) {                                 // the band-pair launch's partners did not meet (placement / dispatch order not as assumed): the
-        c->band_pair_off = true;                  // same call again with one launch per layer, same arithmetic; pairing stays off for this context
-        ++c->gen;                                 // (a streaming graph captured with the pair launch is re-captured by the re-run below)
+    // Structural fall-backs first (same arithmetic, fewer assumptions about dispatch): 5 = a consumer of the overlapped dual path gave up
+    // waiting for the time-axis launch beside it -> launch after launch; 4 = the band-pair launch's partners did not meet (placement /
+    // dispatch order not as assumed) -> one launch per layer.  Each sticks to the context; at most one re-run per kind.
+    int vv = v;
+    for (int tries = 0; tries < 2 && (vv == 4 || vv == 5); ++tries) {
+        if (vv == 4) c->band_pair_off = true; else c->overlap_off = true;
+        ++c->gen;                                 // (a streaming graph captured with the old flow is re-captured by the re-run)
         if (int rc4 = rerun()) return rc4;
         HIP_TRY(hipStreamSynchronize(s));
-        const int v4 = *(volatile int*)c->h_range;
-        if (!v4) return 0;
+        vv = *(volatile int*)c->h_range;
+        if (!vv) return 0;
         *(volatile int*)c->h_range = 0;
-        if (v4 == 3 || v4 == 4) return fail(BSRNN_EHIP, "a recurrent launch gave up waiting on its partners (internal error)");
     }
+    if (vv == 3 || vv == 4 || vv == 5) return fail(BSRNN_EHIP, "a recurrent launch gave up waiting on its partners (internal error, guard value %d)", vv);
     set_force_f32(true);
     const int rc = rerun();
     set_force_f32(false);
@@ -712,6 +883,12 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
         if (e == hipSuccess) { *c->h_range = 0; e = hipHostGetDevicePointer((void**)&c->d_range, c->h_range, 0); }
         if (e != hipSuccess) { c->h_range = nullptr; c->d_range = nullptr; (void)hipGetLastError(); }
     }
+    if (const char* e = getenv("BSRNN_OVERLAP")) {
+        c->overlap_env = strcmp(e, "0") != 0; c->overlap_sabotage = !strcmp(e, "timeout");
+        if (!strcmp(e, "band")) c->overlap_mode = 1;
+        if (!strcmp(e, "mask")) c->overlap_mode = 2;
+        if (!strcmp(e, "pub")) c->overlap_mode = 3 | 4;
+    }
     if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(0, std::min(MAX_PARTS, atoi(e)));
     if (const char* e = getenv("BSRNN_PART_LAG")) c->part_lag = std::max(0, std::min((int)MS_COUNT, atoi(e)));
 
@@ -767,6 +944,10 @@ static void destroy_now(bsrnn_ctx* c)
         if (c->ev_join[j]) (void)hipEventDestroy(c->ev_join[j]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_ovl_fork) (void)hipEventDestroy(c->ev_ovl_fork);
+    if (c->ev_ovl_join) (void)hipEventDestroy(c->ev_ovl_join);
+    free_ovl_tables(c);
+    if (c->d_ovl) (void)hipFree(c->d_ovl);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_tap) (void)hipFree(c->d_tap);
     if (c->d_arena) (void)hipFree(c->d_arena);
@@ -796,6 +977,20 @@ void bsrnn_destroy(bsrnn_ctx* c)
 int bsrnn_n_bands(const bsrnn_ctx* c) { return c ? c->K : -1; }
 int bsrnn_mlp_fused(const bsrnn_ctx* c) { return c ? (c->fused ? 1 : 0) : -1; }
 int bsrnn_device(const bsrnn_ctx* c) { return c ? c->device : -1; }
+int bsrnn_debug_peek(bsrnn_ctx* c, int32_t which, float* host_out, int64_t nfloats)
+{
+    if (!c || !host_out || nfloats < 0 || which < 0 || which > 4) return fail(BSRNN_EARG, "bsrnn_debug_peek: bad arguments");
+    if (c->device < 0 || !c->d_ws) return fail(BSRNN_ESTATE, "bsrnn_debug_peek: no workspace yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t KH = (size_t)c->K * HID;
+    const float* src[5] = {c->Z0, c->Z1, c->HB1, c->P, c->Yf};
+    const size_t cap[5] = {c->cap_rows * KH, c->cap_rows * KH, c->cap_rows * KH * 2, c->cap_rows * c->LDP, c->cap_rows * c->LDP};
+    if ((size_t)nfloats > cap[which]) return fail(BSRNN_EARG, "bsrnn_debug_peek: the buffer holds %zu floats", cap[which]);
+    HIP_TRY(hipMemcpy(host_out, src[which], (size_t)nfloats * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int bsrnn_overlap_state(const bsrnn_ctx* c) { return !c ? -1 : (c->overlap_off ? 2 : (c->overlap_env ? 1 : 0)); }
 int bsrnn_set_range_policy(bsrnn_ctx* c, int32_t policy)
 {
     if (!c) return fail(BSRNN_EARG, "null context");
@@ -1316,7 +1511,7 @@ int bsrnn_forward(bsrnn_ctx* c, const float* x, float* y, float* mask, int32_t C
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
     const size_t M = (size_t)C * T;
-    if ((rc = ensure_ws(c, M)) || (rc = ensure_tasks(c, (int)M))) return rc;
+    if ((rc = ensure_ws(c, M)) || (rc = ensure_tasks(c, (int)M)) || (rc = ensure_ovl(c, C, T))) return rc;
     if (mask && (rc = ensure_tap(c, M))) return rc;
     auto run = [&]() -> int {
         { StageScope sc(c, ST_LAYOUT, s); launch_to_frame_major(c->tb, x, c->Xf, C, T, s); }
@@ -1342,7 +1537,7 @@ int bsrnn_forward_chunk(bsrnn_ctx* c, const float* x, const float* state_in, flo
     hipStream_t s = (hipStream_t)stream;
     ENTER_CALL(c, s);
     const size_t M = (size_t)C * L;
-    if ((rc = ensure_ws(c, M)) || (rc = ensure_tasks(c, (int)M))) return rc;
+    if ((rc = ensure_ws(c, M)) || (rc = ensure_tasks(c, (int)M)) || (rc = ensure_ovl(c, C, L))) return rc;
     if (state_in == state_out && c->range_policy == BSRNN_RANGE_EXACT)
         return fail(BSRNN_EARG, "bsrnn_forward_chunk: state_in and state_out must be different buffers (a call that leaves the fp16 range is run again from state_in)");
     auto run = [&]() -> int {
@@ -1699,6 +1894,7 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
         int ms[MAX_PARTS];
         for (int j = 0; j < parts; ++j) ms[j] = ((int)((int64_t)R * (j + 1) / parts) - (int)((int64_t)R * j / parts)) * T;
         if ((rc = ensure_tasks(c, ms, parts))) return rc;
+        if (parts == 1 && (rc = ensure_ovl(c, R, T))) return rc;
     }
     for (int j = 0; j < parts; ++j) {
         const int r0 = (int)((int64_t)R * j / parts), r1 = (int)((int64_t)R * (j + 1) / parts);
@@ -1713,8 +1909,10 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
             HIP_TRY(hipEventRecord(c->ev_fork, s));
             for (int j = 0; j < parts; ++j) HIP_TRY(hipStreamWaitEvent(c->aux[j], c->ev_fork, 0));
         }
+        const bsrnn_ctx::OvlTable* tb = parts == 1 ? ovl_table(c, R, T) : nullptr;
+        if (tb) run_overlapped(c, pt[0], tb, MS_STFT, MS_ISTFT);      // the dual path overlapped on the context's auxiliary stream
         const int lag = c->part_lag;
-        for (int step = 0; step < MS_COUNT + lag * (parts - 1); ++step)
+        for (int step = 0; !tb && step < MS_COUNT + lag * (parts - 1); ++step)
             for (int j = 0; j < parts; ++j) {
                 const int st = step - lag * j;
                 if (st >= 0 && st < MS_COUNT) run_stage(c, pt[j], st);

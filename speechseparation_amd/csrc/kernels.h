@@ -108,10 +108,52 @@ struct ChainLaunch {
     float* tap; int ldt;             // MASK: the mask itself (optional)
     int* range_flag;
     unsigned long long* dbg;         // measurement only (CHAIN_TRACE builds of tools/chain_bench.hip): per-wave phase stamps
+    // MASK chain launched BESIDE the time-axis launch that produces its input (api.hip, overlapped dual path): every workgroup first
+    // waits until the frames of its rows have left that launch (OvlConsumer below); null = the input is complete at launch
+    const int* ovl_prog; int ovl_T, ovl_K, ovl_spin;
 };
 // rows per workgroup of a descriptor (32 RT GR; 256 for a constant band)
-inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : (d.RT >= 3 ? 16 * d.RT : 32 * d.RT * (8 / d.NW)); }   // RT >= 3: row tiles of 16 (16 x 16 x 32 geometry: 48 or 80 rows)
+__host__ __device__ inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : (d.RT >= 3 ? 16 * d.RT : 32 * d.RT * (8 / d.NW)); }   // RT >= 3: row tiles of 16 (16 x 16 x 32 geometry: 48 or 80 rows)
 void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
+
+// ------------------------------------------------------------------ overlapped dual path (api.hip: run_overlapped)
+// A time-axis launch is causal and the launch behind it (the next band block, the mask chain) works frame by frame, so that launch is
+// started on a second stream BESIDE the time-axis launch - on the 64 CUs its 192 workgroups leave idle and on every CU one of them
+// frees - and each of its workgroups waits until the frames of its own rows have left the time-axis launch:
+//   producer (time_lstm_h2w_kernel): resident[0] += 1 per workgroup at its start (the consumer launch is gated on ALL of them being
+//       resident, so a waiting consumer can never keep a producer off the chip); every output row is stored write-through (sc1);
+//       prog[wg] += 1 for every finished group of four steps, by the last of the four storing waves behind each one's vmcnt(0);
+//   consumer: one lane polls prog[] of the time workgroups that own its rows (relaxed agent-scope loads, bounded), one agent-scope
+//       acquire, workgroup barrier, then plain loads (cdna_hip_programming.md, Guideline 16).  A wait that expires is REPORTED (range
+//       flag value 5: api.hip runs the call again launch after launch and stops overlapping), never computed with.
+// All words are zeroed in stream order before the producers of a call start; nothing travels by value that changes from call to call.
+struct OvlProducer { int* resident; int* prog; };
+struct OvlConsumer { const int* prog; int T; int spin_limit; const int* order; };   // order (band launch): dispatch ordinal -> tile of 16 sequences, by the time its frames are ready
+constexpr int OVL_SPIN_LIMIT = 1 << 22;        // polls (each followed by s_sleep) before a wait gives up: seconds
+void launch_ovl_gate(const int* resident, int target, int* range_flag, int spin_limit, hipStream_t stream);
+#if defined(__HIPCC__)
+// frame rows m_first .. m_last (m = batch row * T + frame) of bands k_first .. k_last: wait until every time-axis workgroup that owns one
+// of those sequences (n = batch row * K + band, four per workgroup) has published the groups that cover the frames.  ONE lane calls this.
+__device__ __forceinline__ bool ovl_wait_rows(const int* prog, int m_first, int m_last, int T, int K, int k_first, int k_last, int limit)
+{
+    typedef const int __attribute__((address_space(1)))* gci;
+    const gci pg = (gci)prog;
+    const int r_a = m_first / T, r_b = m_last / T;
+    int spins = 0;
+    for (int r = r_a; r <= r_b; ++r) {
+        const int t_last = r < r_b ? T - 1 : m_last - r * T;
+        const int need = (t_last >> 2) + 1;
+        for (int wg = (r * K + k_first) >> 2; wg <= (r * K + k_last) >> 2; ++wg)
+            while (__hip_atomic_load(pg + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > limit) return false;
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // this CU's L1 holds nothing older than the poll
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ... once the invalidate has completed (the caller's barrier follows)
+    return true;
+}
+#endif
 
 // ------------------------------------------------------------------ dual-path LSTM kernels
 // Band-axis BLSTM layer (both directions in one launch): N sequences of length L.
@@ -134,7 +176,8 @@ bool band_fc_in_parts();
 // first launch and otherwise only touched by these launches.
 bool band_pair_enabled();
 void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
-                      int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags);
+                      int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags,
+                      const OvlConsumer* ovl = nullptr);
 // The whole band-axis block (both layers, both directions, fc + residual) of a few sequences in one workgroup: the streaming
 // step's N = C frame rows.  w0pk16 / w1pk16 / bias0 / bias1 are launch_band_lstm's arguments of the two layers; fc16 the block's
 // fc (128 -> 64) as fp16x2 B fragments [4 tile][4 blk][2 piece][64 lane][8], fcb its bias.  zout = fc(h1) + b + zin.
@@ -155,7 +198,8 @@ int lstm_mode();
 //         (the shares of the preceding band block's fc, see launch_band_lstm); hout must then be a different buffer than zin.
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,
-                      const void* fc16 = nullptr, const float* fcb = nullptr, const float* part = nullptr);
+                      const void* fc16 = nullptr, const float* fcb = nullptr, const float* part = nullptr,
+                      const OvlProducer* ovl = nullptr);   // ovl: with fc16 / fcb / part only (the fused launch of the parts flow)
 bool time_lstm_fuses_fc();
 
 // ------------------------------------------------------------------ training step, part 1: recurrent layers (lstm_train.hip)

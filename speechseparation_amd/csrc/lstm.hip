@@ -32,6 +32,9 @@
 #ifndef BAND_NO_PLANES
 #define BAND_NO_PLANES 0            // measurement only: 1 = fp32 instead of fp16 planes between the two band layers (A/B, tools/precision_dual_path.py)
 #endif
+#ifndef OVL_DBG
+#define OVL_DBG 0                   // measurement only (overlapped dual path, tools/overlap_variants.sh): 1 a consumer tile sleeps ~20 us behind its wait, 2 the pair hand-over acquires at agent scope, 4 the time kernel's summed rows are stored write-through
+#endif
 #ifndef BAND_ABL
 #define BAND_ABL 0                // measurement only (tools/lstm_h2_trace.hip): bit 1 no x staging, 2 no global h store, 4 no h publish, 8 no step barrier, 16 no MFMAs, 32 no transcendentals
 #endif
@@ -500,7 +503,7 @@ __device__ __forceinline__ void band_layer_body(char* const lds, const int dir, 
 // Workgroup -> (tile of 16 sequences, direction).  The two directions of a tile read the same x rows: in the 1-D grid of
 // launch_band_lstm they are 8 workgroup ids apart - the same XCD (id % 8), dispatched together - so the second read of a row
 // is served by that XCD's L2 instead of a second trip to memory (2-D grids, the measurement tools': direction = blockIdx.y).
-__device__ __forceinline__ bool band_tile_of_block(int N, int& dir, int& tile)
+__device__ __forceinline__ bool band_tile_of_block(int N, int& dir, int& tile, const int* __restrict__ order = nullptr)
 {
     dir = blockIdx.y; tile = blockIdx.x;
     if (gridDim.y == 1) {
@@ -508,7 +511,10 @@ __device__ __forceinline__ bool band_tile_of_block(int N, int& dir, int& tile)
         dir = w >> 3;
         tile = (blockIdx.x >> 4) * 8 + (w & 7);
     }
-    return tile * 16 < N;
+    // overlapped dual path: the dispatch ordinal picks its tile from a table sorted by the time the tile's frames leave the time-axis
+    // launch running beside this one (the pair of a tile keeps its place: 8 workgroup ids apart); -1 pads the table to whole groups
+    if (order) tile = order[tile];
+    return tile >= 0 && tile * 16 < N;
 }
 
 template <int IN, bool TRACE = false, bool PART = false>
@@ -538,13 +544,28 @@ __global__ __launch_bounds__(256, 2) void band_pair_h2_kernel(const float* __res
                                                               const uint4* __restrict__ w1, const float* __restrict__ b1,
                                                               int N, int L, int* __restrict__ range_flag,
                                                               const uint4* __restrict__ wfc, const float* __restrict__ bfc,
-                                                              int* flags, int sabotage)
+                                                              int* flags, int sabotage, OvlConsumer ovl)
 {
     constexpr int B0 = BandLds<HID, false>::BYTES, B1 = BandLds<2 * HID, PART>::BYTES;
     __shared__ __attribute__((aligned(16))) char lds[B0 > B1 ? B0 : B1];
     __shared__ int partner_ok;
     int dir, tile;
-    if (!band_tile_of_block(N, dir, tile)) return;
+    if (!band_tile_of_block(N, dir, tile, ovl.order)) return;
+    if (ovl.prog) {
+        // launched beside the time-axis launch that writes z (kernels.h, OvlConsumer): wait until this tile's 16 frame rows have left it
+        if (threadIdx.x == 0) {
+            const int m_last = tile * 16 + 15 < N ? tile * 16 + 15 : N - 1;
+            partner_ok = ovl_wait_rows(ovl.prog, tile * 16, m_last, ovl.T, L, 0, L - 1, ovl.spin_limit) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!partner_ok) {                        // (value 5: api.hip runs the call again launch after launch and stops overlapping)
+            if (threadIdx.x == 0 && range_flag) *range_flag = 5;
+            return;
+        }
+        __syncthreads();                          // (partner_ok is written again below)
+        if (OVL_DBG & 1)
+            for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     band_layer_body<HID, false, false>(lds, dir, tile, z, hb0, w0, b0, N, L, range_flag, nullptr, nullptr, nullptr);
     // Hand-over through the XCD's L2, which both workgroups share: a store is counted out of vmcnt when L2 has it, so vmcnt(0) is
     // all the release this needs (an agent-scope release fence would write the whole L2 back for the sake of other XCDs: measured,
@@ -569,6 +590,8 @@ __global__ __launch_bounds__(256, 2) void band_pair_h2_kernel(const float* __res
         return;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (orders the plane loads below behind the poll)
+    if (OVL_DBG & 2) { asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    else
     asm volatile("buffer_inv sc0" ::: "memory");                 // the partner's planes from L2, not from a line this CU's L1 may hold
     band_layer_body<2 * HID, false, PART>(lds, dir, tile, hb0, hb1, w1, b1, N, L, range_flag, nullptr, wfc, bfc);
 }
@@ -580,19 +603,21 @@ bool band_pair_enabled()
 }
 // both layers of a band block as one launch (band_pair_h2_kernel); fc16 / fcb as launch_band_lstm's (shares of the fc) or null
 void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
-                      int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags)
+                      int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags, const OvlConsumer* ovlp)
 {
     if (N <= 0 || L <= 0) return;
+    OvlConsumer ovl = {nullptr, 0, 0, nullptr};
+    if (ovlp) ovl = *ovlp;
     const dim3 grid((((N + 15) / 16 + 7) / 8) * 16), block(256);
     // test hook (tests/test_gpu_edges.py): BSRNN_BAND_PAIR=mismatch makes every workgroup publish a wrong XCC id, as if its partner sat on
     // another XCD - the launch reports it (guard value 4) and the context falls back to one launch per layer
     static const int sabotage = [] { const char* e = getenv("BSRNN_BAND_PAIR"); return (e && !strcmp(e, "mismatch")) ? 1 : 0; }();
     if (fc16)
         hipLaunchKernelGGL((band_pair_h2_kernel<true>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
-                           range_flag, (const uint4*)fc16, fcb, flags, sabotage);
+                           range_flag, (const uint4*)fc16, fcb, flags, sabotage, ovl);
     else
         hipLaunchKernelGGL((band_pair_h2_kernel<false>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
-                           range_flag, (const uint4*)nullptr, (const float*)nullptr, flags, sabotage);
+                           range_flag, (const uint4*)nullptr, (const float*)nullptr, flags, sabotage, ovl);
 }
 
 // BSRNN_BAND_FC = part (default: the second band layer writes the two directions' shares of the block's fc, the time-axis launch adds
@@ -1093,7 +1118,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                                                              const uint4* __restrict__ wfc, const float* __restrict__ bfc,
                                                              const float* __restrict__ state_in, float* __restrict__ state_out,
                                                              int R, int T, int K, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
-                                                             const float* __restrict__ part = nullptr)
+                                                             const float* __restrict__ part = nullptr, int* ovl_resident = nullptr, int* ovl_prog = nullptr)
 {
     unsigned long long tp[4] = {0, 0, 0, 0}, tq = 0;          // measurement only
     auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
@@ -1104,6 +1129,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) uint4 wflds[FUSE ? 4 * 4 * 64 : 1];
     __shared__ int sync[SY_COUNT];            // the counters (and the abort word) of lds_wait_ge / lds_arrive
     __shared__ float hb_lds[PART ? 512 : 1];  // PART: the helpers' biases [layer][gate][unit]
+    __shared__ int outc[8];                   // overlapped dual path: storing waves that have drained group f, in slot f & 7 (monotonic: 4 per use)
 
     const int N = R * K;
     const int n0 = blockIdx.x * 4;
@@ -1125,6 +1151,9 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
     const int bstep = n & 3;                     // ... batched form: step (l & 15) & 3 of the group
     const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
     if (tid < SY_COUNT) sync[tid] = 0;
+    if (tid >= 64 && tid < 72) outc[tid - 64] = 0;
+    // overlapped dual path (kernels.h, OvlProducer): this workgroup is on the chip - the launch that consumes its output is let go when all are
+    if (tid == 0 && ovl_resident) __hip_atomic_fetch_add(ovl_resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
 
     // The two role families are laid out as "helpers: ...; return;  main waves: ..." and not as if / else: with a join behind both, the
@@ -1261,7 +1290,13 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                     // overwrites it with the block's result: one read of the three rows instead of two.  Same workgroup, same CU:
                     // the store is complete (vmcnt(0) in front of this wave's PIN0 arrival below) long before the chain H0 -> M0 ->
                     // H1 of LDS counters lets H1 ask for it, and nobody has read that line before (no stale copy in the L1).
-                    if (n0 + xs_i < N && 4 * g + xs_t < T) *reinterpret_cast<float4*>(hout + rows_of(g)) = make_float4(f[0], f[1], f[2], f[3]);
+                    if (n0 + xs_i < N && 4 * g + xs_t < T) {
+                        if (OVL_DBG & 4) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) __hip_atomic_store((float __attribute__((address_space(1)))*)(hout + rows_of(g) + e), f[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else
+                        *reinterpret_cast<float4*>(hout + rows_of(g)) = make_float4(f[0], f[1], f[2], f[3]);
+                    }
                 };
                 // Only the residual row (4 registers) is in flight across an input half; the two share rows of the next group are
                 // requested BEHIND it and land during the waits at the top of the next iteration: the kernel must stay inside 128
@@ -1304,6 +1339,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                 if (g >= 2) lds_wait_ge(sync, SY_DONE0, 16 * (g - 1));   // layer 0 has finished group g - 2 (same buffer)
                 stamp(0);
                 input_half(xslot(4 * g), g);
+                if (g) lds_wait_ge(sync, SY_PIN0, 4 * g);             // (SY_PIN0 is a sum over the four waves: no wave two groups ahead of another, see H1)
                 lds_arrive(&sync[SY_PIN0], lane);
                 stamp(2);
             }
@@ -1325,7 +1361,20 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                     xres[e] = res_src[row + unit];
                 }
             };
+            // Overlapped dual path: the output rows of group f are in memory (every store of them write-through, this wave's drained by the
+            // vmcnt(0) here; the last of the four storing waves to say so for f tells the consumers - each wave works through the groups in
+            // order and drains all its older stores with it, so f + 1 published groups mean groups 0 .. f are complete whichever wave
+            // published them).  Called one group late, where the wave waits for its residual loads anyway: no extra stall on H1.
+            const bool pub = FUSE && ovl_prog != nullptr;
+            auto publish = [&](int f) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(&outc[f & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if ((old & 3) == 3 && lane == 0) __hip_atomic_fetch_add(ovl_prog + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
             auto fc_finish = [&](int f) {
+                if (pub && f >= 1) publish(f - 1);
                 const int ffirst = 4 * f, nst = T - ffirst < 4 ? T - ffirst : 4;
                 const _Float16* mine = &h1pl[((ffirst & (H1RING - 1)) + bstep) * TSTEP];
                 v4f fhi = zero4, flo = zero4;
@@ -1343,9 +1392,12 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                 lds_arrive(&sync[SY_FC], lane);                       // the group's h1 slots are free again
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (e < nst && nq_raw < N)
-                        hout[base_q + (size_t)(ffirst + e) * tstride + unit] =
-                            ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + xres[e];
+                    if (e < nst && nq_raw < N) {
+                        const float v = ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + xres[e];
+                        float* const dst = hout + base_q + (size_t)(ffirst + e) * tstride + unit;
+                        if (pub) __hip_atomic_store((float __attribute__((address_space(1)))*)dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dword sc1
+                        else *dst = v;
+                    }
             };
             __syncthreads();
             for (int g = 0; g < G; ++g) {
@@ -1354,6 +1406,15 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                 if (g >= 2) lds_wait_ge(sync, SY_DONE1, 16 * (g - 1));   // layer 1 has finished group g - 2 (same buffer; its h1 is complete)
                 stamp(0);
                 input_half(&h0pl[((4 * g) & (H0RING - 1)) * TSTEP], g);
+                // SY_PIN1 and SY_FC are SUMS over the four H1 waves, and their waiters (M1: this group's input half is published; M0 / M1:
+                // a ring slot has been read) conclude "every wave has done group g" from "sum >= 4 (g + 1)".  That only holds while no wave
+                // is two groups ahead of another - and nothing else ties the H1 waves to each other: one of them stalled for a few
+                // microseconds on global memory (its residual loads, its output stores) while the other three went on gave M1 a group
+                // whose input half - or an h1 slot whose fc read - was the stalled wave's old one: 16 units of four sequences slightly
+                // wrong from a group boundary on.  Seen once in ~100 calls with write-through output stores (overlapped dual path,
+                // tools/overlap_probe.py), and the likely cause of round 3's "result depended on a second process starting" (DESIGN 4e).
+                // So a wave publishes group g only when all four have published g - 1: skew <= 1 group, for which the sums are exact.
+                if (g) lds_wait_ge(sync, SY_PIN1, 4 * g);
                 lds_arrive(&sync[SY_PIN1], lane);
                 stamp(2);
                 if (FUSE) {
@@ -1367,6 +1428,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                 fc_request(G - 1);
                 lds_wait_ge(sync, SY_DONE1, 4 * T);
                 fc_finish(G - 1);
+                if (pub) publish(G - 1);
             }
         }
         finish();
@@ -1688,7 +1750,7 @@ static bool parts_add_mode()
 
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,
-                      const void* fc16, const float* fcb, const float* part)
+                      const void* fc16, const float* fcb, const float* part, const OvlProducer* ovl)
 {
     const int N = R * K;
     if (N <= 0 || T <= 0) return;
@@ -1701,7 +1763,8 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const voi
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
         if (time_lstm_fuses_fc() && fc16 && fcb && part)
             hipLaunchKernelGGL((time_lstm_h2w_kernel<true, false, true>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
-                               state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr, part);
+                               state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr, part, ovl ? ovl->resident : (int*)nullptr,
+                               ovl ? ovl->prog : (int*)nullptr);
         else if (time_lstm_fuses_fc() && fc16 && fcb)
             hipLaunchKernelGGL((time_lstm_h2w_kernel<true, false>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
                                state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr);
@@ -1715,6 +1778,23 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const voi
     }
     hipLaunchKernelGGL(time_lstm_kernel, grid, block, 0, stream, zin, hout, wpk, bias, state_in, state_out, R, T, K,
                        (unsigned long long*)nullptr);
+}
+
+// Gate of the overlapped dual path (kernels.h): ONE wave that leaves when every workgroup of the time-axis launch on the other stream is
+// resident; the consumer launch follows it in stream order, so no consumer workgroup can take a CU a producer still needs.
+__global__ void ovl_gate_kernel(const int* resident, int target, int* range_flag, int limit)
+{
+    if (threadIdx.x) return;
+    typedef const int __attribute__((address_space(1)))* gci;
+    int spins = 0;
+    while (__hip_atomic_load((gci)resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > limit) { if (range_flag) *range_flag = 5; return; }
+    }
+}
+void launch_ovl_gate(const int* resident, int target, int* range_flag, int spin_limit, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ovl_gate_kernel, dim3(1), dim3(64), 0, stream, resident, target, range_flag, spin_limit);
 }
 
 }  // namespace bsrnn

@@ -762,6 +762,20 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
     const int2 task = g.tasks[blockIdx.x];
     const int di = task.x, row0 = task.y;
     const ChainDesc* const dp = g.desc + di;
+    if (CHAIN == CHAIN_MASK && g.ovl_prog) {
+        // launched beside the time-axis launch that writes the chain's input (kernels.h, OvlConsumer): wait until the frames of this
+        // workgroup's rows of this band have left it
+        __shared__ int ovl_ok;
+        if (threadIdx.x == 0) {
+            const int rows = chain_rows(*dp), m_last = row0 + rows - 1 < g.M ? row0 + rows - 1 : g.M - 1, band = dp->z_off / HID;
+            ovl_ok = ovl_wait_rows(g.ovl_prog, row0, m_last, g.ovl_T, g.ovl_K, band, band, g.ovl_spin) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!ovl_ok) {                            // (value 5: api.hip runs the call again launch after launch and stops overlapping)
+            if (threadIdx.x == 0 && g.range_flag) *g.range_flag = 5;
+            return;
+        }
+    }
     if (dp->constant) {
         // TrainableConstantModule (bsrnn.py:12-24): the zero-width band's feature is one learned vector for every frame
         if (CHAIN == CHAIN_SPLIT) {

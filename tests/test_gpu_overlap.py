@@ -1,0 +1,107 @@
+"""The overlapped dual path (csrc/api.hip::run_overlapped, kernels.h OvlProducer / OvlConsumer): the second band block runs beside the
+first time-axis launch and the mask chain beside the second, on an auxiliary stream, each consumer workgroup waiting for the frames of
+its own rows.  Same kernels and arithmetic as the serial flow, another dispatch order: every result must be EQUAL to BSRNN_OVERLAP=0,
+call after call, also beside other work on the GPU; a consumer whose bounded wait expires is reported and the call falls back."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model(sd, overlap):
+    """A model whose context is created under BSRNN_OVERLAP=<overlap> (read once per context, csrc/api.hip::bsrnn_create)."""
+    from speechseparation_amd.bsrnn import BSRNN
+    old = os.environ.get("BSRNN_OVERLAP")
+    if overlap is None:
+        os.environ.pop("BSRNN_OVERLAP", None)
+    else:
+        os.environ["BSRNN_OVERLAP"] = overlap
+    try:
+        m = BSRNN().eval()
+        m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd.items()}, strict=True)
+        m = m.to("cuda")
+        m._context(torch.device("cuda", torch.cuda.current_device()))
+    finally:
+        if old is None:
+            os.environ.pop("BSRNN_OVERLAP", None)
+        else:
+            os.environ["BSRNN_OVERLAP"] = old
+    return m
+
+
+@pytest.fixture(scope="module")
+def models(sd_hot):
+    return make_model(sd_hot, None), make_model(sd_hot, "0")
+
+
+def test_overlapped_dual_path_equals_the_serial_flow_bit_for_bit(models):
+    from speechseparation_amd import weights
+    ovl, ser = models
+    assert ovl.overlap_state() == 1 and ser.overlap_state() == 0
+    # the metric's configuration (64 rows x 8 s @ 16 kHz: T = 126, 192 time-axis workgroups, 504 band tiles of which 63 straddle two rows)
+    w = torch.from_numpy(weights.synth_waveform(64, 128000, seed=5)).cuda()
+    ref = ser.separate(w).cpu().numpy()
+    for i in range(6):
+        assert np.array_equal(ovl.separate(w).cpu().numpy(), ref), "call %d" % i
+    # the reference's operator (with the mask) on a ragged batch: 17 rows x 77 frames (51 time-axis workgroups, the last one ragged)
+    x = ser.stft(torch.from_numpy(weights.synth_waveform(17, 76 * 1024 + 300, seed=6)).cuda())
+    y0, m0 = ser.forward_with_mask(x)
+    y1, m1 = ovl.forward_with_mask(x)
+    assert torch.equal(y0, y1) and torch.equal(m0, m1)
+    # a chunk with carried state (causal time axis): 16 rows x 64 frames
+    xc = x[:16, :, :64].contiguous()
+    s = torch.from_numpy(np.random.default_rng(3).standard_normal((4, 2, 16 * 12, 64)).astype(np.float32) * 0.3).cuda()
+    z0, s0 = ser.forward_chunk(xc, s)
+    z1, s1 = ovl.forward_chunk(xc, s)
+    assert torch.equal(z0, z1) and torch.equal(s0, s1)
+    assert ovl.overlap_state() == 1          # nothing gave up
+
+
+def test_overlapped_results_do_not_depend_on_other_work_on_the_gpu(models):
+    """Hand-offs inside a launch are to be tested under UNEVEN load with every word checked (cdna_hip_programming.md, Guideline 16):
+    large matrix products on a second torch stream start and stop while the overlapped calls run."""
+    from speechseparation_amd import weights
+    ovl, ser = models
+    w = torch.from_numpy(weights.synth_waveform(48, 100 * 1024 + 11, seed=7)).cuda()
+    ref = ser.separate(w).cpu().numpy()
+    a = torch.randn(4096, 4096, device="cuda")
+    side = torch.cuda.Stream()
+    outs = []
+    for i in range(24):
+        if i % 3 != 2:
+            with torch.cuda.stream(side):
+                for _ in range(1 + i % 4):
+                    a = torch.tanh(a @ a * 1e-3)
+        outs.append(ovl.separate(w))
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy(), ref), "call %d" % i
+    assert ovl.overlap_state() == 1
+
+
+def test_a_consumer_that_gives_up_is_reported_and_the_call_falls_back(sd_hot):
+    """BSRNN_OVERLAP=timeout (test hook): the time-axis launches publish no progress and the consumers' waits are cut to ~2 ms - every
+    consumer workgroup gives up (guard value 5).  The call must notice, run again launch after launch and return the right numbers with
+    rc 0; the context stays on the serial flow."""
+    from speechseparation_amd import weights
+    ser = make_model(sd_hot, "0")
+    bad = make_model(sd_hot, "timeout")
+    assert bad.overlap_state() == 1
+    w = torch.from_numpy(weights.synth_waveform(16, 40 * 1024 + 5, seed=8)).cuda()
+    ref = ser.separate(w).cpu().numpy()
+    assert np.array_equal(bad.separate(w).cpu().numpy(), ref)
+    assert bad.overlap_state() == 2
+    assert np.array_equal(bad.separate(w).cpu().numpy(), ref)
+    # under the 'deferred' policy nothing waits: the next call reports it (and that context stops overlapping, too)
+    from speechseparation_amd._native import NativeError
+    bad2 = make_model(sd_hot, "timeout")
+    bad2.set_range_policy("deferred")
+    bad2.separate(w)
+    torch.cuda.synchronize()
+    with pytest.raises(NativeError):
+        bad2.separate(w)
+    assert bad2.overlap_state() == 2
+    assert np.array_equal(bad2.separate(w).cpu().numpy(), ref)
