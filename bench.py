@@ -40,7 +40,8 @@ DOMINANT = ("bandsplit_mlp", "mask_mlp")
 DTYPE_LABEL = {
     "f32": "f32 (exact fp32 MFMA)",
     "fp16x2": "f32 io/accumulate, fp16x2-split operands (22-bit operands, 3 f16 MFMA terms; a2*b2 term dropped)",
-    "fp16": "f16 operands, f32 accumulate/io (REDUCED PRECISION configuration; BASELINE config 2 names bf16: this is the fp16 one-term mode, 3 more mantissa bits than bf16)",
+    "fp16": "f16 operands, f32 accumulate/io (REDUCED PRECISION configuration; the fp16 one-term mode: 3 more mantissa bits than the bf16 BASELINE config 2 names, range guard)",
+    "bf16": "bf16 operands in the per-band MLPs, f32 accumulate/io, LSTMs fp16x2 (REDUCED PRECISION configuration: BASELINE config 2 as named)",
 }
 
 
@@ -111,11 +112,13 @@ def host_cores():
 FUSED_LAUNCH_MIX = {        # mlp_chain_kernel<chain (0 BandSplit, 1 MaskEstimation), MFMA terms>
     "fp16x2": (("mlp_chain_kernel<0, 3>", 1), ("mlp_chain_kernel<1, 3>", 1)),
     "fp16": (("mlp_chain_kernel<0, 1>", 1), ("mlp_chain_kernel<1, 1>", 1)),
+    "bf16": (("mlp_chain_kernel<0, -1>", 1), ("mlp_chain_kernel<1, -1>", 1)),
 }
 GEMM_LAUNCH_MIX = {
     "f32": (("gemm_f32_kernel<1,", 8), ("gemm_f32_kernel<0,", 1), ("gemm_f32_kernel<3,", 1)),
     "fp16x2": (("gemm_h2_kernel<1, 2,", 6), ("gemm_h2_kernel<1, 1,", 2), ("gemm_h2_kernel<0, 1,", 1), ("gemm_h2_kernel<3, 2,", 1)),
     "fp16": (("gemm_h2_kernel<1, 2, 0, 1>", 6), ("gemm_h2_kernel<1, 1, 0, 1>", 2), ("gemm_h2_kernel<0, 1, 0, 1>", 1), ("gemm_h2_kernel<3, 2, 0, 1>", 1)),
+    "bf16": (("gemm_h2_kernel<1, 2,", 6), ("gemm_h2_kernel<1, 1,", 2), ("gemm_h2_kernel<0, 1,", 1), ("gemm_h2_kernel<3, 2,", 1)),
 }
 # matrix-pipe roofline of the grouped GEMM per mode: (kernel, peak in algorithmic TFLOP/s, how it is derived)
 GEMM_ROOF = {
@@ -123,6 +126,8 @@ GEMM_ROOF = {
     "fp16x2": ("gemm_h2_kernel", 2500.0 / 3, "f16 MFMA dense peak 2500 TFLOP/s / 3 MFMA terms per fp32-accurate product "
                "(a1b1 + a1b2 + a2b1, fp32 accumulate)"),
     "fp16": ("gemm_h2_kernel<fp16, 1 term>", 2500.0, "f16 MFMA dense peak; REDUCED PRECISION (plain fp16 operands, ~5e-4 relative per product): "
+             "not the fp32-accurate default"),
+    "bf16": ("mlp_chain_kernel<bf16, 1 term>", 2500.0, "bf16 MFMA dense peak; REDUCED PRECISION (plain bf16 operands, ~4e-3 relative per product): "
              "not the fp32-accurate default"),
 }
 

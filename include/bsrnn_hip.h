@@ -115,6 +115,11 @@ int  bsrnn_overlap_state(const bsrnn_ctx* ctx);
  * host (synchronises the device).  which: 0 = Z0, 1 = Z1 (the dual-path tensor's two buffers, [rows*frames][K][64]), 2 = HB1 (the
  * band blocks' fc shares, [rows*frames][K][2][64]), 3 = P, 4 = Yf (band-padded rows of LDP floats). */
 int  bsrnn_debug_peek(bsrnn_ctx* ctx, int32_t which, float* host_out, int64_t nfloats);
+/* Process-wide counts of what the library has done that does not belong on a real-time thread: which = 0 device / pinned / stream
+ * allocations, 1 stream captures begun, 2 graph instantiations, 3 graph launches.  A bsrnn_stream does all of the first three in
+ * bsrnn_stream_create (as the reference's plugin does in its constructor, speech-ladspa-onnx.cpp:55-120); its step calls leave them
+ * unchanged (tests/test_gpu_entrypoints.py drives the LADSPA plugin's run() and checks). */
+long long bsrnn_debug_counter(int32_t which);
 
 /* ---- parameters ---------------------------------------------------------------------
  * Replaces `load_state_dict` (infer.py:19, infer-streaming.py:46): parameters are named
@@ -275,6 +280,9 @@ int  bsrnn_evaluate(bsrnn_ctx* ctx, const float* mix_dev, const float* speech_de
 /* ---- streaming (infer-streaming.py:84-147; speech-ladspa-onnx.cpp:171-267) -------------
  * A bsrnn_stream owns, on the device, the sliding 2048-sample analysis buffer, the LSTM
  * state [4,2,C*K,64] and the previous synthesis frame for C rows.
+ * bsrnn_stream_create does ALL first-use work (allocations, loading every kernel, capturing and instantiating the step's
+ * hipGraphs: two throw-away steps on zero input, carry zeroed again afterwards), so that the first bsrnn_stream_step* call
+ * costs what every later one costs.
  * bsrnn_stream_step: chunk_dev [C, 1024] -> out_dev [C, 1024] (delayed by one chunk):
  *     rfft(buf*hann) -> forward_recurrent -> irfft -> 2-slot overlap-add / sum(window).
  * bsrnn_stream_step_host: same with host buffers, synchronous (used by the LADSPA plugin);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "bsrnn_lstm_train_forward", "bsrnn_lstm_train_backward", "bsrnn_linear_train_forward", "bsrnn_linear_train_backward",
     "bsrnn_istft_backward", "bsrnn_adamw_step", "bsrnn_adamw_step_multi", "bsrnn_adamw_step_multi_dev",
     "bsrnn_linear_group_train_forward", "bsrnn_linear_group_train_backward",
-    "bsrnn_set_range_policy", "bsrnn_get_range_policy", "bsrnn_overlap_state", "bsrnn_debug_peek",
+    "bsrnn_set_range_policy", "bsrnn_get_range_policy", "bsrnn_overlap_state", "bsrnn_debug_peek", "bsrnn_debug_counter",
 ]
 RANGE_DEFERRED, RANGE_EXACT = 0, 1          # BSRNN_RANGE_* of include/bsrnn_hip.h
 METRIC_NAMES = ("loss", "sdr", "input_sdr", "sisdr", "l1_time", "l1_re", "l1_im", "separation_db")   # BSRNN_M_* order
@@ -58,6 +58,7 @@ def _load():
         "bsrnn_mlp_fused": (C.c_int, [vp]),
         "bsrnn_overlap_state": (C.c_int, [vp]),
         "bsrnn_debug_peek": (C.c_int, [vp, i32, vp, i64]),
+        "bsrnn_debug_counter": (C.c_longlong, [i32]),
         "bsrnn_param_count": (C.c_int, [vp]),
         "bsrnn_param_info": (C.c_int, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
         "bsrnn_set_param": (C.c_int, [vp, C.c_char_p, vp, i64]),

@@ -19,6 +19,12 @@
 
 using namespace bsrnn;
 
+// --------------------------------------------------------------------------- first-use accounting (bsrnn_debug_counter)
+// What the library has done that does not belong on a real-time thread: device / pinned allocations, stream captures, graph
+// instantiations.  Process-wide; tests read them around the LADSPA plugin's run() (tests/test_gpu_entrypoints.py).
+static std::atomic<long long> g_dbg[4];
+enum { DBG_ALLOC = 0, DBG_CAPTURE = 1, DBG_INSTANTIATE = 2, DBG_GRAPH_LAUNCH = 3 };
+
 // --------------------------------------------------------------------------- error plumbing
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...)
@@ -322,6 +328,7 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
                               seg(rows / 8 + 2 * MAX_PARTS + 64)};
     size_t total = 0;
     for (size_t s : sizes) total += s;
+    ++g_dbg[DBG_ALLOC];
     HIP_TRY(hipMalloc((void**)&c->d_ws, total * sizeof(float)));
     // pad columns (band segments are 16-byte aligned, rows padded) are read as K-padding by the GEMM and are
     // never written afterwards: they must be finite, so the whole workspace starts at zero
@@ -339,6 +346,7 @@ int ensure_tap(bsrnn_ctx* c, size_t rows)
     if (rows <= c->tap_rows) return 0;
     HIP_TRY(hipDeviceSynchronize());
     if (c->d_tap) { HIP_TRY(hipFree(c->d_tap)); c->d_tap = nullptr; }
+    ++g_dbg[DBG_ALLOC];
     HIP_TRY(hipMalloc((void**)&c->d_tap, rows * c->LDP * sizeof(float)));
     c->tap_rows = rows;
     ++c->gen;
@@ -349,7 +357,7 @@ int ensure_streams(bsrnn_ctx* c, int parts)
 {
     if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int j = 0; j < parts; ++j) {
-        if (!c->aux[j]) HIP_TRY(hipStreamCreateWithFlags(&c->aux[j], hipStreamNonBlocking));
+        if (!c->aux[j]) { ++g_dbg[DBG_ALLOC]; HIP_TRY(hipStreamCreateWithFlags(&c->aux[j], hipStreamNonBlocking)); }
         if (!c->ev_join[j]) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[j], hipEventDisableTiming));
     }
     return 0;
@@ -392,6 +400,7 @@ int ensure_tasks(bsrnn_ctx* c, const int* Ms, int n)
         for (int ch = 0; ch < 2; ++ch) {
             build_chain_tasks(c, ch, Ms[i], h);
             t.n[ch] = (int)h.size();
+            ++g_dbg[DBG_ALLOC];
             hipError_t e = hipMalloc((void**)&t.d[ch], (h.size() + 1) * sizeof(int2));
             if (e == hipSuccess) e = hipMemcpy(t.d[ch], h.data(), h.size() * sizeof(int2), hipMemcpyHostToDevice);
             if (e != hipSuccess) {
@@ -437,6 +446,7 @@ struct Part {
     const float* wave; float* wave_out; int64_t n;       // only for the fused sandwich
     const bsrnn_ctx::OvlTable* ovl;                      // non-null: the overlapped flow (run_overlapped) - producers publish, consumers wait
     int ovl_mode;                                        // ... which of the two hand-overs (bsrnn_ctx::overlap_mode)
+    int ovl_zero_blk;                                    // the band block (0 / 1) whose launch clears the progress words, -1: none
 };
 
 Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s, int j = 0)
@@ -509,7 +519,8 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
             if (cons)                             // beside the first time-axis launch: tiles in the order their frames leave it
                 oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 4096 : OVL_SPIN_LIMIT, p.ovl->band_order};
             launch_band_pair(zi, p.HB0, p.HB1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1], M, K, c->d_range, s,
-                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr);
+                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr,
+                             p.ovl && p.ovl_zero_blk == blk ? c->d_ovl : nullptr, 2 * c->ovl_stride);
             break;
         }
         launch_band_lstm(zi, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
@@ -613,6 +624,7 @@ int ensure_ovl(bsrnn_ctx* c, int C, int T)
     if (stride > c->ovl_stride) {
         HIP_TRY(hipDeviceSynchronize());
         if (c->d_ovl) { HIP_TRY(hipFree(c->d_ovl)); c->d_ovl = nullptr; }
+        ++g_dbg[DBG_ALLOC];
         HIP_TRY(hipMalloc((void**)&c->d_ovl, (size_t)2 * stride * sizeof(int)));
         HIP_TRY(hipMemset(c->d_ovl, 0, (size_t)2 * stride * sizeof(int)));
         c->ovl_stride = stride;
@@ -679,11 +691,11 @@ void run_overlapped(bsrnn_ctx* c, Part p, const bsrnn_ctx::OvlTable* tb, int fir
     p.ovl = tb;
     p.ovl_mode = c->overlap_mode;
     const bool band = p.ovl_mode & 1, mask = p.ovl_mode & 2, serial = p.ovl_mode & 4;
+    p.ovl_zero_blk = band ? 0 : 1;                // the last band launch in front of the fork clears the progress words
     Part pb = p;
     if (!serial) pb.s = B;
     const int nwg = (p.C * c->K + 3) / 4, limit = OVL_SPIN_LIMIT;
     for (int st = first; st <= MS_BANDSPLIT; ++st) run_stage(c, p, st);
-    (void)hipMemsetAsync(c->d_ovl, 0, (size_t)2 * c->ovl_stride * sizeof(int), A);
     run_stage(c, p, MS_BAND0);
     auto fork = [&]() { if (!serial) { (void)hipEventRecord(c->ev_ovl_fork, A); (void)hipStreamWaitEvent(B, c->ev_ovl_fork, 0); } };
     auto join = [&]() { if (!serial) { (void)hipEventRecord(c->ev_ovl_join, B); (void)hipStreamWaitEvent(A, c->ev_ovl_join, 0); } };
@@ -841,7 +853,7 @@ const char* bsrnn_compute_mode(void)
 {
     static char buf[64];
     const int g = gemm_mode(), l = lstm_mode();
-    snprintf(buf, sizeof buf, "gemm=%s lstm=%s", g == GEMM_F32 ? "f32" : (g == GEMM_FP16X2 ? "fp16x2" : "fp16"),
+    snprintf(buf, sizeof buf, "gemm=%s lstm=%s", g == GEMM_F32 ? "f32" : (g == GEMM_FP16X2 ? "fp16x2" : (g == GEMM_BF16 ? "bf16" : "fp16")),
              l == LSTM_F32 ? "f32" : "fp16x2");
     return buf;
 }
@@ -990,6 +1002,7 @@ int bsrnn_debug_peek(bsrnn_ctx* c, int32_t which, float* host_out, int64_t nfloa
     HIP_TRY(hipMemcpy(host_out, src[which], (size_t)nfloats * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
+long long bsrnn_debug_counter(int32_t which) { return which >= 0 && which < 4 ? g_dbg[which].load() : -1; }
 int bsrnn_overlap_state(const bsrnn_ctx* c) { return !c ? -1 : (c->overlap_off ? 2 : (c->overlap_env ? 1 : 0)); }
 int bsrnn_set_range_policy(bsrnn_ctx* c, int32_t policy)
 {
@@ -1257,8 +1270,9 @@ int bsrnn_commit_params(bsrnn_ctx* c)
                 const Param& w = P_(c, std::string(b) + ".weight");
                 const Param& bi = P_(c, std::string(b) + ".bias");
                 d.L[l].w_off = (unsigned)(stream.size() * sizeof(uint16_t));
-                if (g48) pack_chain_layer16_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, 8, gmode == GEMM_FP16 ? 1 : 2, stream);
-                else pack_chain_layer_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, d.NW, gmode == GEMM_FP16 ? 1 : 2, stream, d.L[l].rag);
+                const int npl = (gmode == GEMM_FP16 || gmode == GEMM_BF16) ? 1 : 2;
+                if (g48) pack_chain_layer16_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, 8, npl, stream, gmode == GEMM_BF16);
+                else pack_chain_layer_host(w.data.data(), ld[l].N, ld[l].Kd, ld[l].Kd, d.NW, npl, stream, d.L[l].rag, gmode == GEMM_BF16);
                 memcpy(&biases[d.L[l].bias_off], bi.data.data(), ld[l].N * sizeof(float));
             }
             stream.resize((stream.size() + 7) & ~size_t(7), 0);
@@ -2049,6 +2063,7 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     const size_t nstate = (size_t)4 * 2 * C * c->K * HID;
     const size_t total = stream_total_floats(c, C);
     float* p = nullptr;
+    ++g_dbg[DBG_ALLOC];
     hipError_t e = hipMalloc((void**)&p, total * sizeof(float));
     if (e != hipSuccess) { delete st; return fail(BSRNN_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
     st->base = p;
@@ -2070,8 +2085,21 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     if (e != hipSuccess) { (void)hipFree(st->base); delete st; return fail(BSRNN_EHIP, "hipMemset: %s", hipGetErrorString(e)); }
     rc = ensure_ws(c, C);
     if (!rc) rc = ensure_tasks(c, C);
-    if (rc) { (void)hipFree(st->base); delete st; return rc; }
+    if (rc) { (void)hipHostFree(st->h_in); (void)hipHostFree(st->h_out); (void)hipFree(st->base); delete st; return rc; }
     ++c->live_streams;
+    // Everything a first step would otherwise do on the caller's (audio) thread happens here, as the reference does in its constructor
+    // (speech-ladspa-onnx.cpp:55-120: session, FFT plans, state): one throw-away step per carry parity through the host-buffer entry
+    // point - it loads every kernel's code object, captures and instantiates both parity graphs and touches the pinned staging
+    // buffers - then the carry sets are zeroed again.  bsrnn_stream_step / _step_host allocate, capture and instantiate nothing
+    // afterwards unless the context's workspace or weights change under the stream (generation counter).
+    {
+        std::vector<float> zero((size_t)C * HOPS, 0.f), sink((size_t)C * HOPS);
+        for (int k = 0; k < 2 && !rc; ++k) rc = bsrnn_stream_step_host(st, zero.data(), sink.data(), 1.0f);
+        if (!rc && hipMemset(st->base, 0, total * sizeof(float)) != hipSuccess) rc = fail(BSRNN_EHIP, "hipMemset failed");
+        if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(BSRNN_EHIP, "hipDeviceSynchronize failed");
+        st->cur = 0;
+        if (rc) { bsrnn_stream_destroy(st); return rc; }
+    }
     *out = st;
     return 0;
 }
@@ -2125,15 +2153,29 @@ static int stream_step_run(bsrnn_stream* st, const float* chunk, float* out, flo
             stream_drop_graph(st);
         }
         if (!st->exec[p]) {
-            if (!st->cap) HIP_TRY(hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking));
+            if (!st->cap) { ++g_dbg[DBG_ALLOC]; HIP_TRY(hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking)); }
+            ++g_dbg[DBG_CAPTURE];
             HIP_TRY(hipStreamBeginCapture(st->cap, hipStreamCaptureModeThreadLocal));
             rc = run_model(c, st->X, st->Y, nullptr, st->C, 1, st->state[p], st->state[q], st->cap);
-            hipError_t e = hipStreamEndCapture(st->cap, &st->graph[p]);
-            if (rc) return rc;
-            if (e != hipSuccess) return fail(BSRNN_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            HIP_TRY(hipGraphInstantiate(&st->exec[p], st->graph[p], nullptr, nullptr, 0));
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamEndCapture(st->cap, &g);           // (always ended, whatever run_model said: the stream must leave capture mode)
+            if (rc || e != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);                       // a failed capture leaves nothing behind
+                (void)hipGetLastError();
+                if (rc) return rc;
+                return fail(BSRNN_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            }
+            ++g_dbg[DBG_INSTANTIATE];
+            e = hipGraphInstantiate(&st->exec[p], g, nullptr, nullptr, 0);
+            if (e != hipSuccess) {
+                (void)hipGraphDestroy(g);
+                st->exec[p] = nullptr;
+                return fail(BSRNN_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+            }
+            st->graph[p] = g;
             st->gen = c->gen;
         }
+        ++g_dbg[DBG_GRAPH_LAUNCH];
         HIP_TRY(hipGraphLaunch(st->exec[p], s));
     } else if ((rc = run_model(c, st->X, st->Y, nullptr, st->C, 1, st->state[p], st->state[q], s))) {
         return rc;

@@ -664,7 +664,8 @@ int gemm_mode()
         if (!e || !*e || !strcmp(e, "fp16x2")) return (int)GEMM_FP16X2;
         if (!strcmp(e, "f32")) return (int)GEMM_F32;
         if (!strcmp(e, "fp16")) return (int)GEMM_FP16;
-        fprintf(stderr, "bsrnn: unknown BSRNN_GEMM='%s' (f32 | fp16x2 | fp16), using fp16x2\n", e);
+        if (!strcmp(e, "bf16")) return (int)GEMM_BF16;
+        fprintf(stderr, "bsrnn: unknown BSRNN_GEMM='%s' (f32 | fp16x2 | fp16 | bf16), using fp16x2\n", e);
         return (int)GEMM_FP16X2;
     }();
     return mode;
@@ -675,6 +676,7 @@ void launch_gemm(const GemmLaunch& g, hipStream_t stream)
     if (g.M <= 0 || g.n_tiles <= 0) return;
     switch (force_f32() ? (int)GEMM_F32 : gemm_mode()) {
     case GEMM_FP16X2:
+    case GEMM_BF16:                 // (bf16 operands exist in the fused chains only, kernels.h)
         if (g.tile_n == 128) launch_gemm_h2<2>(g, stream);
         else launch_gemm_h2<1>(g, stream);
         return;

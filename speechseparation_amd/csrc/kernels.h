@@ -57,7 +57,9 @@ void launch_gemv(const GemmLaunch& g, hipStream_t stream);
 // fp16 = plain 16-bit operands, one MFMA term, fp32 accumulate (the reduced-precision configuration, not the default).
 // The fp32 weights are always resident beside the fp16 pieces: a call whose operands left the fp16x2 range is re-run on
 // the exact-fp32 kernels (set_force_f32, per host thread) by the synchronous entry points of api.hip.
-enum GemmMode { GEMM_F32 = 0, GEMM_FP16 = 1, GEMM_FP16X2 = 2 };
+// bf16 = plain bf16 operands, one MFMA term, in the fused MLP chains (BASELINE config 2 as it is named; no range limit, 8 significant
+// bits); the few launches outside the chains (a band too wide for the LDS image, the block fc of the BSRNN_BAND_FC=gemm flow) then run fp16x2.
+enum GemmMode { GEMM_F32 = 0, GEMM_FP16 = 1, GEMM_FP16X2 = 2, GEMM_BF16 = 3 };
 int gemm_mode();
 void set_force_f32(bool on);
 bool force_f32();
@@ -177,7 +179,7 @@ bool band_fc_in_parts();
 bool band_pair_enabled();
 void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
                       int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags,
-                      const OvlConsumer* ovl = nullptr);
+                      const OvlConsumer* ovl = nullptr, int* zero_words = nullptr, int zero_n = 0);   // zero_words: progress words to clear (overlapped dual path)
 // The whole band-axis block (both layers, both directions, fc + residual) of a few sequences in one workgroup: the streaming
 // step's N = C frame rows.  w0pk16 / w1pk16 / bias0 / bias1 are launch_band_lstm's arguments of the two layers; fc16 the block's
 // fc (128 -> 64) as fp16x2 B fragments [4 tile][4 blk][2 piece][64 lane][8], fcb its bias.  zout = fc(h1) + b + zin.

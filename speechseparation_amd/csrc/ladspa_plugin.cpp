@@ -11,7 +11,9 @@
 // Changed on purpose: the model file is the flat weight file named by $BSRNN_WEIGHTS (default
 // ./model-always.bsrnnw) instead of a hard-coded ONNX path (:73); instantiate() returns NULL
 // on any failure and nothing throws across the C ABI (the reference logs and may dereference
-// null, :117-119); no allocation happens in run().
+// null, :117-119); run() allocates, compiles and captures nothing: instantiate() has done all of it (bsrnn_stream_create runs two
+// throw-away steps: every kernel loaded, both parity graphs captured and instantiated, carry zeroed again) - as the reference's
+// constructor builds its session, FFT plans and state (:55-120) and its run() only uses them (:152-169).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

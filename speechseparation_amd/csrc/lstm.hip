@@ -544,11 +544,15 @@ __global__ __launch_bounds__(256, 2) void band_pair_h2_kernel(const float* __res
                                                               const uint4* __restrict__ w1, const float* __restrict__ b1,
                                                               int N, int L, int* __restrict__ range_flag,
                                                               const uint4* __restrict__ wfc, const float* __restrict__ bfc,
-                                                              int* flags, int sabotage, OvlConsumer ovl)
+                                                              int* flags, int sabotage, OvlConsumer ovl, int* zero_words, int zero_n)
 {
     constexpr int B0 = BandLds<HID, false>::BYTES, B1 = BandLds<2 * HID, PART>::BYTES;
     __shared__ __attribute__((aligned(16))) char lds[B0 > B1 ? B0 : B1];
     __shared__ int partner_ok;
+    // overlapped dual path: the progress words of the launches BEHIND this one are zeroed here, in stream order in front of their
+    // producers and consumers (a memset of their own cost the stream 5 us plus two launch gaps)
+    if (zero_words && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_n; i += 256) zero_words[i] = 0;
     int dir, tile;
     if (!band_tile_of_block(N, dir, tile, ovl.order)) return;
     if (ovl.prog) {
@@ -603,7 +607,8 @@ bool band_pair_enabled()
 }
 // both layers of a band block as one launch (band_pair_h2_kernel); fc16 / fcb as launch_band_lstm's (shares of the fc) or null
 void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
-                      int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags, const OvlConsumer* ovlp)
+                      int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags, const OvlConsumer* ovlp,
+                      int* zero_words, int zero_n)
 {
     if (N <= 0 || L <= 0) return;
     OvlConsumer ovl = {nullptr, 0, 0, nullptr};
@@ -614,10 +619,10 @@ void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16
     static const int sabotage = [] { const char* e = getenv("BSRNN_BAND_PAIR"); return (e && !strcmp(e, "mismatch")) ? 1 : 0; }();
     if (fc16)
         hipLaunchKernelGGL((band_pair_h2_kernel<true>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
-                           range_flag, (const uint4*)fc16, fcb, flags, sabotage, ovl);
+                           range_flag, (const uint4*)fc16, fcb, flags, sabotage, ovl, zero_words, zero_n);
     else
         hipLaunchKernelGGL((band_pair_h2_kernel<false>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
-                           range_flag, (const uint4*)nullptr, (const float*)nullptr, flags, sabotage, ovl);
+                           range_flag, (const uint4*)nullptr, (const float*)nullptr, flags, sabotage, ovl, zero_words, zero_n);
 }
 
 // BSRNN_BAND_FC = part (default: the second band layer writes the two directions' shares of the block's fc, the time-axis launch adds
@@ -1153,7 +1158,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
     if (tid < SY_COUNT) sync[tid] = 0;
     if (tid >= 64 && tid < 72) outc[tid - 64] = 0;
     // overlapped dual path (kernels.h, OvlProducer): this workgroup is on the chip - the launch that consumes its output is let go when all are
-    if (tid == 0 && ovl_resident) __hip_atomic_fetch_add(ovl_resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PART && tid == 0 && ovl_resident) __hip_atomic_fetch_add(ovl_resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
 
     // The two role families are laid out as "helpers: ...; return;  main waves: ..." and not as if / else: with a join behind both, the
@@ -1365,7 +1370,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
             // vmcnt(0) here; the last of the four storing waves to say so for f tells the consumers - each wave works through the groups in
             // order and drains all its older stores with it, so f + 1 published groups mean groups 0 .. f are complete whichever wave
             // published them).  Called one group late, where the wave waits for its residual loads anyway: no extra stall on H1.
-            const bool pub = FUSE && ovl_prog != nullptr;
+            const bool pub = FUSE && PART && ovl_prog != nullptr;       // (only the parts flow overlaps: api.hip)
             auto publish = [&](int f) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 int old = 0;

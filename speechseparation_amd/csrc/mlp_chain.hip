@@ -70,6 +70,29 @@ constexpr int PD = CHAIN_PD;
 #define CHAIN_PD48 4               // prefetch depth of the 48-row geometry (its k-steps carry two tiles' fragments)
 #endif
 
+// One-term bf16 mode (BSRNN_GEMM=bf16, TERMS = -1 in the templates below): the 16-bit containers of the LDS images and of the weight
+// fragments hold bf16 instead of fp16 (same size, same layouts); activations are rounded to nearest even (v_cvt_pk_bf16_f32) and the
+// products run on v_mfma_f32_*_bf16.  No range limit, 8 significant bits: BASELINE config 2 as it is named.
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ h4 to_bf16_bits(v4f a)
+{
+    return __builtin_bit_cast(h4, __builtin_convertvector(a, bf4));
+}
+template <int TERMS>
+__device__ __forceinline__ v16f mfma32(const h8 a, const h8 b, const v16f c)
+{
+    if (TERMS == -1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <int TERMS>
+__device__ __forceinline__ v4f mfma16(const h8 a, const h8 b, const v4f c)
+{
+    if (TERMS == -1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int TERMS> __device__ __forceinline__ void split4t(v4f a, h4& p0, h4& p1);
 __device__ __forceinline__ void split4(v4f a, h4& p0, h4& p1)
 {
     // identical to Piece<2>::split of gemm.hip: a1 = fp16(a), a2 = fp16(fma(-a1, 2048, 2048 a)); the empty asm keeps the
@@ -80,13 +103,18 @@ __device__ __forceinline__ void split4(v4f a, h4& p0, h4& p1)
 #pragma unroll
     for (int i = 0; i < 4; ++i) p1[i] = (_Float16)__builtin_fmaf(-(float)p0[i], 2048.f, a[i] * 2048.f);
 }
+template <int TERMS> __device__ __forceinline__ void split4t(v4f a, h4& p0, h4& p1)
+{
+    if (TERMS == -1) { asm("" : "+v"(a)); p0 = to_bf16_bits(a); p1 = p0; }
+    else split4(a, p0, p1);
+}
 
 // The body of one workgroup: GR groups of NW = 8 / GR waves; a group owns RT row tiles (compile-time: they size the
 // accumulators) and its waves share the feature tiles.  Rows per workgroup = 32 RT GR.
 template <int CHAIN, int TERMS, int RT, int GR>
 __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc* const dp, const int row0, char* const smem_all)
 {
-    constexpr int NPL = TERMS == 1 ? 1 : 2;       // pieces per operand
+    constexpr int NPL = (TERMS == 1 || TERMS == -1) ? 1 : 2;       // pieces per operand
     constexpr int NW = 8 / GR;
     // prefetch depth: register sets of weight fragments in flight (fewer where two row tiles' accumulators take the room)
     constexpr int PDR = RT == 1 ? PD : (PD < 4 ? PD : 4);
@@ -196,7 +224,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
                     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
                     h4 p0, p1;
-                    split4(x, p0, p1);
+                    split4t<TERMS>(x, p0, p1);
                     *reinterpret_cast<h4*>(smem + r * img + u * 512 + m * 16 + 8 * h) = p0;
                     if (NPL == 2) *reinterpret_cast<h4*>(smem + r * img + plane + u * 512 + m * 16 + 8 * h) = p1;
                 }
@@ -251,10 +279,10 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
 #pragma unroll
                             for (int pc = 0; pc < NPL; ++pc) b[pc] = *reinterpret_cast<const h8*>(smem + r * img + pc * plane + ks * 1024 + lane * 16);
                             if (NPL == 2) {
-                                lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[sx][0], b[NPL - 1], lo[r], 0, 0, 0);
-                                lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[sx][NPL - 1], b[0], lo[r], 0, 0, 0);
+                                lo[r] = mfma32<TERMS>(w[sx][0], b[NPL - 1], lo[r]);
+                                lo[r] = mfma32<TERMS>(w[sx][NPL - 1], b[0], lo[r]);
                             }
-                            hi[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[sx][0], b[0], hi[r], 0, 0, 0);
+                            hi[r] = mfma32<TERMS>(w[sx][0], b[0], hi[r]);
                         }
                         if (s0 + sx + PDR < kr) wload(sx, rp + (size_t)(s0 + sx + PDR) * STEP);
                         else if (cnt > 0 && sx < K16) wload(sx, wp + (size_t)sx * STEP);            // the first whole tile comes next
@@ -267,7 +295,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                 for (int r = 0; r < RT; ++r) {
                     v4f pv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pv[e] = TERMS == 1 ? hi[r][e] : hi[r][e] + (1.f / 2048.f) * lo[r][e];
+                    for (int e = 0; e < 4; ++e) pv[e] = NPL == 1 ? hi[r][e] : hi[r][e] + (1.f / 2048.f) * lo[r][e];
                     rscr[(wn * RT + r) * 32 + m] = pv;
                 }
             }
@@ -325,10 +353,10 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                         for (int pc = 0; pc < NPL; ++pc) b[r][pc] = *reinterpret_cast<const h8*>(smem + r * img + pc * plane + ks * 1024 + lane * 16);
                         if (r + 1 < RT) __builtin_amdgcn_sched_barrier(0);
                         if (NPL == 2) {
-                            lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][0], b[r][NPL - 1], lo[r], 0, 0, 0);
-                            lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][NPL - 1], b[r][0], lo[r], 0, 0, 0);
+                            lo[r] = mfma32<TERMS>(w[set][0], b[r][NPL - 1], lo[r]);
+                            lo[r] = mfma32<TERMS>(w[set][NPL - 1], b[r][0], lo[r]);
                         }
-                        hi[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][0], b[r][0], hi[r], 0, 0, 0);
+                        hi[r] = mfma32<TERMS>(w[set][0], b[r][0], hi[r]);
                         if (r + 1 < RT) __builtin_amdgcn_sched_barrier(0);
                     }
                     return;
@@ -340,10 +368,10 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
                     if (NPL == 2) {
-                        lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][0], b[r][NPL - 1], lo[r], 0, 0, 0);      // w1 x2
-                        lo[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][NPL - 1], b[r][0], lo[r], 0, 0, 0);      // w2 x1
+                        lo[r] = mfma32<TERMS>(w[set][0], b[r][NPL - 1], lo[r]);      // w1 x2
+                        lo[r] = mfma32<TERMS>(w[set][NPL - 1], b[r][0], lo[r]);      // w2 x1
                     }
-                    hi[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[set][0], b[r][0], hi[r], 0, 0, 0);                // w1 x1
+                    hi[r] = mfma32<TERMS>(w[set][0], b[r][0], hi[r]);                // w1 x1
                 }
             };
             int ks0 = 0;
@@ -380,7 +408,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                     v4f v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float sum = TERMS == 1 ? hi[r][4 * q + e] : hi[r][4 * q + e] + (1.f / 2048.f) * lo[r][4 * q + e];
+                        const float sum = NPL == 1 ? hi[r][4 * q + e] : hi[r][4 * q + e] + (1.f / 2048.f) * lo[r][4 * q + e];
                         v[e] = sum + bv[e];
                         if (leaky) v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
                     }
@@ -388,7 +416,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                         amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
                         amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
                         h4 p0, p1;
-                        split4(v, p0, p1);
+                        split4t<TERMS>(v, p0, p1);
                         held[last ? 0 : c][r][q][0] = p0;
                         held[last ? 0 : c][r][q][NPL - 1] = NPL == 2 ? p1 : p0;
                         if (to_p && row_ok[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0) = v;
@@ -425,7 +453,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
                     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
                     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
                     h4 p0, p1;
-                    split4(v, p0, p1);
+                    split4t<TERMS>(v, p0, p1);
                     const h4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
                     char* const d = smem + r * img + (4 * t) * 512 + m * 16 + 8 * h;
                     *reinterpret_cast<h4*>(d) = p0;                       // k-unit 4 t: features n0 .. n0 + 7
@@ -484,7 +512,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
         for (int i = 0; i < nstamp && i < 24; ++i) d[i] = tstamp[i];
     }
     // range guard (see gemm.hip): a finite operand beyond the fp16 range saturated its first piece
-    if (amax > 65504.f && g.range_flag) *g.range_flag = 1;
+    if (TERMS != -1 && amax > 65504.f && g.range_flag) *g.range_flag = 1;      // (bf16 has the range of fp32)
 }
 
 // The widest bands (more than 576 columns: the 768-wide band of the 12-band table) on v_mfma_f32_16x16x32_f16: 48 frame
@@ -501,7 +529,7 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
 template <int CHAIN, int TERMS, int RT = 3, int CTR = 6, int PDR = CHAIN_PD48, int TP = 2>
 __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDesc* const dp, const int row0, char* const smem)
 {
-    constexpr int NPL = TERMS == 1 ? 1 : 2;
+    constexpr int NPL = (TERMS == 1 || TERMS == -1) ? 1 : 2;
     constexpr int NW = 8, ROWS = 16 * RT, UB = ROWS * 16;      // UB: bytes of one k-unit (8 k) of one piece
                                                   // (PDR k-steps in flight; a step is TWO feature tiles' fragments, 4 KB per wave)
     // TP: feature tiles per pass over K: each activation fragment read from LDS feeds TP tiles (LDS read bandwidth is the
@@ -584,7 +612,7 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
                     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
                     h4 p0, p1;
-                    split4(x, p0, p1);
+                    split4t<TERMS>(x, p0, p1);
                     char* const d = smem + u * UB + (16 * r + m) * 16 + 8 * (gq & 1);
                     *reinterpret_cast<h4*>(d) = p0;
                     if (NPL == 2) *reinterpret_cast<h4*>(d + plane) = p1;
@@ -666,10 +694,10 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
 #pragma unroll
                     for (int r = 0; r < RT; ++r) {
                         if (NPL == 2) {
-                            lo[tt][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[set][tt][0], b[r][NPL - 1], lo[tt][r], 0, 0, 0);      // w1 x2
-                            lo[tt][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[set][tt][NPL - 1], b[r][0], lo[tt][r], 0, 0, 0);      // w2 x1
+                            lo[tt][r] = mfma16<TERMS>(w[set][tt][0], b[r][NPL - 1], lo[tt][r]);      // w1 x2
+                            lo[tt][r] = mfma16<TERMS>(w[set][tt][NPL - 1], b[r][0], lo[tt][r]);      // w2 x1
                         }
-                        hi[tt][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[set][tt][0], b[r][0], hi[tt][r], 0, 0, 0);                // w1 x1
+                        hi[tt][r] = mfma16<TERMS>(w[set][tt][0], b[r][0], hi[tt][r]);                // w1 x1
                     }
                 }
                 if (!(CHAIN_ABL & 4)) bload(ks + 1 < K32 ? ks + 1 : ks);
@@ -707,7 +735,7 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                 v4f v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float sum = TERMS == 1 ? hi[tt][r][e] : hi[tt][r][e] + (1.f / 2048.f) * lo[tt][r][e];
+                    const float sum = NPL == 1 ? hi[tt][r][e] : hi[tt][r][e] + (1.f / 2048.f) * lo[tt][r][e];
                     v[e] = sum + bv[e];
                     if (leaky) v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
                 }
@@ -715,7 +743,7 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
                     amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
                     h4 p0, p1;
-                    split4(v, p0, p1);
+                    split4t<TERMS>(v, p0, p1);
                     held[last ? 0 : c + tt][r][0] = p0;
                     held[last ? 0 : c + tt][r][NPL - 1] = NPL == 2 ? p1 : p0;
                     if (to_p && rokl[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0) = v;
@@ -751,7 +779,7 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
 #pragma unroll 1
     for (int l = 0; l < CHAIN_LAYERS - 1; ++l) layer(std::false_type(), l);
     layer(std::true_type(), CHAIN_LAYERS - 1);
-    if (amax > 65504.f && g.range_flag) *g.range_flag = 1;
+    if (TERMS != -1 && amax > 65504.f && g.range_flag) *g.range_flag = 1;      // (bf16 has the range of fp32)
 }
 
 template <int CHAIN, int TERMS>
@@ -814,12 +842,14 @@ void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream)
 {
     if (g.M <= 0 || g.n_tasks <= 0) return;
     dim3 grid(g.n_tasks), block(512);
-    const bool one = gemm_mode() == GEMM_FP16;
+    const int mode = gemm_mode();
     if (chain == CHAIN_SPLIT) {
-        if (one) hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_SPLIT, 1>), grid, block, 0, stream, g);
+        if (mode == GEMM_FP16) hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_SPLIT, 1>), grid, block, 0, stream, g);
+        else if (mode == GEMM_BF16) hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_SPLIT, -1>), grid, block, 0, stream, g);
         else hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_SPLIT, 3>), grid, block, 0, stream, g);
     } else {
-        if (one) hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_MASK, 1>), grid, block, 0, stream, g);
+        if (mode == GEMM_FP16) hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_MASK, 1>), grid, block, 0, stream, g);
+        else if (mode == GEMM_BF16) hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_MASK, -1>), grid, block, 0, stream, g);
         else hipLaunchKernelGGL((mlp_chain_kernel<CHAIN_MASK, 3>), grid, block, 0, stream, g);
     }
 }

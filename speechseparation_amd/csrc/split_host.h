@@ -91,7 +91,8 @@ inline int chain_rag_first(int K16, int NW, int wn)
     const int base = K16 / NW, rem = K16 - base * NW;
     return wn * base + (wn < rem ? wn : rem);
 }
-inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out, int rag = 0)
+// bf = true (npl = 1 only): the one piece is bf16 instead of fp16 (BSRNN_GEMM=bf16)
+inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out, int rag = 0, bool bf = false)
 {
     const int K16 = (K + 15) / 16, NTL = (N + 31) / 32 - rag;
     auto frag = [&](int t, int ks, int pc) {
@@ -101,7 +102,7 @@ inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW,
                 const float v = (n < N && k < K) ? w[(size_t)n * ldw + k] : 0.f;
                 uint16_t p[2];
                 split_planes_host(&v, 1, 2, p);
-                out.push_back(p[pc]);
+                out.push_back(bf ? bf16_from_float(v) : p[pc]);
             }
     };
     for (int wn = 0; wn < NW; ++wn)
@@ -116,7 +117,7 @@ inline void pack_chain_layer_host(const float* w, int N, int K, int ldw, int NW,
 
 // The same for the 48-row geometry on v_mfma_f32_16x16x32_f16 (feature tiles of 16, k-steps of 32): lane (n = l & 15,
 // kb = l >> 4) holds W[16 t + n][32 ks + 8 kb + j].
-inline void pack_chain_layer16_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out)
+inline void pack_chain_layer16_host(const float* w, int N, int K, int ldw, int NW, int npl, std::vector<uint16_t>& out, bool bf = false)
 {
     const int K32 = (K + 31) / 32, FT = (N + 15) / 16;
     for (int wn = 0; wn < NW; ++wn)
@@ -129,7 +130,7 @@ inline void pack_chain_layer16_host(const float* w, int N, int K, int ldw, int N
                             const float v = (n < N && k < K) ? w[(size_t)n * ldw + k] : 0.f;
                             uint16_t p[2];
                             split_planes_host(&v, 1, 2, p);
-                            out.push_back(p[pc]);
+                            out.push_back(bf ? bf16_from_float(v) : p[pc]);
                         }
 }
 

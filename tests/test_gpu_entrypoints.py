@@ -109,6 +109,46 @@ def test_ladspa_run_matches_oracle(weight_file, sd_default, mix):
     assert err < 1e-4
 
 
+def test_ladspa_run_does_no_first_use_work(weight_file):
+    """The reference builds its session, FFT plans and state in the plugin's constructor and run() only uses them
+    (speech-ladspa-onnx.cpp:55-120, :152-169).  Here instantiate() must have loaded every kernel, captured and instantiated both
+    parity graphs of the streaming step and sized every buffer: the first chunks run() processes allocate, capture and instantiate
+    nothing (process-wide counters of the library) and take no longer than twice a steady-state chunk."""
+    import time
+    from speechseparation_amd import _native, weights
+    os.environ["BSRNN_WEIGHTS"] = weight_file
+    lib = C.CDLL(PLUGIN)
+    lib.ladspa_descriptor.restype = C.POINTER(Descriptor)
+    lib.ladspa_descriptor.argtypes = [C.c_ulong]
+    d = lib.ladspa_descriptor(0).contents
+    counters = lambda: tuple(_native.lib.bsrnn_debug_counter(i) for i in range(3))    # allocations, captures, instantiations
+    before = counters()
+    h = d.instantiate(None, 44100)
+    assert h
+    ready = counters()
+    assert ready[1] - before[1] == 2 and ready[2] - before[2] == 2       # both parity graphs were made in instantiate()
+    launches0 = _native.lib.bsrnn_debug_counter(3)
+    wave = weights.synth_waveform(2, 64 * 1024, seed=9)
+    control = np.array([1.0], np.float32)
+    o1 = np.empty(1024, np.float32); o2 = np.empty(1024, np.float32)
+    times = []
+    for k in range(64):                                                    # one model step per run() call
+        i1 = np.ascontiguousarray(wave[0, 1024 * k:1024 * (k + 1)]); i2 = np.ascontiguousarray(wave[1, 1024 * k:1024 * (k + 1)])
+        d.connect_port(h, 0, fptr(control)); d.connect_port(h, 1, fptr(i1)); d.connect_port(h, 2, fptr(i2))
+        d.connect_port(h, 3, fptr(o1)); d.connect_port(h, 4, fptr(o2))
+        t0 = time.perf_counter()
+        d.run(h, 1024)
+        times.append(time.perf_counter() - t0)
+        if k == 1:
+            assert counters() == ready, "run() allocated, captured or instantiated on its first chunks"
+    assert counters() == ready
+    assert _native.lib.bsrnn_debug_counter(3) - launches0 == 64            # every chunk was a graph replay
+    d.cleanup(h)
+    steady = float(np.median(times[8:]))
+    print("ladspa run(): first chunks %.0f / %.0f us, steady state %.0f us" % (1e6 * times[0], 1e6 * times[1], 1e6 * steady))
+    assert times[0] <= 2.0 * steady + 50e-6 and times[1] <= 2.0 * steady + 50e-6, (times[:4], steady)
+
+
 def test_ladspa_in_place_buffers(weight_file):
     """Hosts may run in place (output buffer == input buffer); the reference reads before it writes."""
     from speechseparation_amd import weights

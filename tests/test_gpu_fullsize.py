@@ -152,14 +152,16 @@ def test_dual_path_flows_agree_at_rounding_level(kind):
             assert rel < 1e-5, (name, k, rel)
 
 
-def test_config2_16bit_gemm_mode_full_size():
-    """BASELINE config 2: R = 32 x 8 s @ 16 kHz with 16-bit GEMM operands (BSRNN_GEMM=fp16: one MFMA term, fp32 accumulate,
-    the LSTMs stay fp16x2) against the fp32-accurate default on the same batch: within 1e-2 of the output range."""
+@pytest.mark.parametrize("gemm,tol", [("fp16", 1e-2), ("bf16", 1.5e-2)])
+def test_config2_16bit_gemm_mode_full_size(gemm, tol):
+    """BASELINE config 2: R = 32 x 8 s @ 16 kHz with 16-bit GEMM operands (BSRNN_GEMM=bf16, as the config names it, and fp16: one
+    MFMA term, fp32 accumulate, the LSTMs stay fp16x2) against the fp32-accurate default on the same batch: within 1e-2 (fp16) /
+    1.5e-2 (bf16: 8 significant bits, measured 3e-3 ... 5e-3; the reference's own bf16 copy is 0.7e-2 of the range from its fp32 forward) of the output range."""
     with tempfile.TemporaryDirectory() as d:
         _, ref = run_child("cfg2", {}, d, "default")
-        out, low = run_child("cfg2", {"BSRNN_GEMM": "fp16"}, d, "fp16")
+        out, low = run_child("cfg2", {"BSRNN_GEMM": gemm}, d, gemm)
     assert "flow: fused" in out
     for k in ("y", "f", "mask"):
         rel = maxabs(low[k], ref[k]) / np.abs(ref[k]).max()
-        print("fp16 GEMM mode, %s: relative to the output range %.2e" % (k, rel))
-        assert np.isfinite(low[k]).all() and rel < 1e-2, (k, rel)
+        print("%s GEMM mode, %s: relative to the output range %.2e" % (gemm, k, rel))
+        assert np.isfinite(low[k]).all() and rel < tol, (k, rel)

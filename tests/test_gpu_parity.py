@@ -211,7 +211,7 @@ def test_errors_are_loud(model):
 def test_compute_mode_is_reported(model):
     from speechseparation_amd import _native
     m = _native.compute_mode()
-    assert m["gemm"] in ("f32", "fp16x2", "fp16") and m["lstm"] in ("f32", "fp16x2")
+    assert m["gemm"] in ("f32", "fp16x2", "fp16", "bf16") and m["lstm"] in ("f32", "fp16x2")
     print("compute mode:", m)
     # the MLP chains run fused unless the exact-fp32 mode or BSRNN_MLP=layers asks for per-layer launches
     want = "layers" if (m["gemm"] == "f32" or os.environ.get("BSRNN_MLP") == "layers") else "fused"

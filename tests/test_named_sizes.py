@@ -182,10 +182,12 @@ def test_hip_chunks_of_256_frames_equal_offline(sd_default):
 
 
 @pytest.mark.gpu
-def test_hip_config2_full_size_against_the_oracle_corner(sd_default):
-    """config 2 as named (R = 32 x 8 s, 16-bit GEMM operands: BSRNN_GEMM=fp16, the one-term fp16 mode standing in for the bf16 the
-    config names) at full size, in a child process (the mode is read once per process): the first frames of two rows against the
-    fp32 oracle run on just those frames (the model is causal in time) - within the mode's stated 1e-2 of the output range."""
+@pytest.mark.parametrize("gemm,tol", [("bf16", 1.5e-2), ("fp16", 1e-2)])
+def test_hip_config2_full_size_against_the_oracle_corner(sd_default, gemm, tol):
+    """config 2 as named (R = 32 x 8 s, bf16 GEMM operands: BSRNN_GEMM=bf16; and the one-term fp16 mode that stood in for it until
+    round 4) at full size, in a child process (the mode is read once per process): the first frames of two rows against the
+    fp32 oracle run on just those frames (the model is causal in time) - within the mode's stated tolerance (fp16 1e-2, bf16 1.5e-2 of
+    the output range: the reference's own bf16 copy measures 8.7e-2 at |y|max ~ 12 against its fp32 forward)."""
     code = r'''
 import sys, numpy as np, torch
 from oracle import bsrnn_numpy as onp
@@ -193,7 +195,7 @@ from speechseparation_amd import weights, _native
 from speechseparation_amd.bsrnn import BSRNN
 sd = weights.synth_state_dict(None, seed=0)
 m = BSRNN().eval(); m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd.items()}); m = m.to("cuda")
-assert _native.compute_mode()["gemm"] == "fp16"
+assert _native.compute_mode()["gemm"] == sys.argv[1]
 w = weights.synth_waveform(32, 128000, seed=1234)
 x = m.stft(torch.from_numpy(w).cuda())
 y = m(x)
@@ -201,9 +203,9 @@ ref = onp.forward(sd, x[:2, :, :8].cpu().numpy())
 rel = float(np.abs(y[:2, :, :8].cpu().numpy() - ref).max() / np.abs(ref).max())
 print("REL", rel, bool(torch.isfinite(y).all()), tuple(y.shape))
 '''
-    env = dict(os.environ, PYTHONPATH=REPO, BSRNN_GEMM="fp16")
-    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, PYTHONPATH=REPO, BSRNN_GEMM=gemm)
+    r = subprocess.run([sys.executable, "-c", code, gemm], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     rel, finite, shape = r.stdout.split("REL")[1].split(None, 2)
-    print("config 2 (fp16 operands) full size vs fp32 oracle on rows 0-1, frames 0-7: %s of the range" % rel)
-    assert float(rel) < 1e-2 and finite == "True" and "(32, 2050, 126)" in shape
+    print("config 2 (%s operands) full size vs fp32 oracle on rows 0-1, frames 0-7: %s of the range" % (gemm, rel))
+    assert float(rel) < tol and finite == "True" and "(32, 2050, 126)" in shape

@@ -36,11 +36,11 @@ def main():
     m = model_for()
     from speechseparation_amd import _native
     mode = _native.compute_mode()
-    if mode["gemm"] == "fp16":     # config 2 as named: 16-bit compute (BSRNN_GEMM=fp16: plain fp16 GEMM operands, fp32 accumulate / I/O)
+    if mode["gemm"] in ("fp16", "bf16"):     # config 2 as named: 16-bit compute (BSRNN_GEMM=bf16 / fp16: plain 16-bit GEMM operands, fp32 accumulate / I/O)
         w = torch.from_numpy(weights.synth_waveform(32, 128000, seed=1234)).cuda()
         out = torch.empty((32, 125 * 1024), device="cuda")
         dt = timed(lambda: m.separate(w, out=out))
-        print(json.dumps({"config": "2: offline R=32 x 8 s @16 kHz, 16-bit GEMM operands (BSRNN_GEMM=fp16, ~1e-3 of the output range)",
+        print(json.dumps({"config": "2: offline R=32 x 8 s @16 kHz, 16-bit GEMM operands (BSRNN_GEMM=%s)" % mode["gemm"],
                           "ms_per_batch": round(dt * 1e3, 4), "row_frames_per_s": round(32 * 126 / dt, 1)}))
         return
     # config 2 in the fp32-accurate default mode
