@@ -88,6 +88,71 @@ def test_long_sequence_causality(sd_default):
     assert maxabs(finals[0], finals[1]) < 2e-5 and maxabs(finals[0], finals[2]) < 2e-5
 
 
+@pytest.mark.parametrize("scale", [1e-4, 1e-6])
+def test_small_inputs_stay_accurate(sd_default, scale):
+    """The reference's fp32 forward has no magnitude floor (bsrnn.py:385-443): quiet audio keeps its relative accuracy.  fp16 pieces go
+    subnormal below 6.1e-5 and vanish below 6e-8, so the split-precision kernels are held, on inputs scaled by 1e-4 and 1e-6 (spectrum
+    values down to ~1e-7 and below), to the float32 oracle's own distance from the float64 evaluation - relative to the output range -
+    for forward, the dual path on its own and waveform -> waveform."""
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    m = make_model(sd_default)
+    x = weights.synth_tensor((2, 2050, 8), seed=21, scale=scale)
+    y64 = onp.forward(sd_default, x, dtype=np.float64)
+    y32 = onp.forward(sd_default, x, dtype=np.float32)
+    y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    rng = np.abs(y64).max()
+    e_hip, e_f32 = maxabs(y, y64) / rng, maxabs(y32, y64) / rng
+    print("forward, inputs x %g: max|y| %.3g  |hip - f64| / range %.2e   |f32 oracle - f64| / range %.2e" % (scale, rng, e_hip, e_f32))
+    assert e_hip <= 3 * e_f32 + 2e-7
+    z = weights.synth_tensor((2, 8, 12, 64), seed=22, scale=scale)
+    z64, _ = onp.dual_path(sd_default, z.astype(np.float64), None, np.float64)
+    z32, _ = onp.dual_path(sd_default, z, None, np.float32)
+    zo, _ = m.dual_path(torch.from_numpy(z).cuda())
+    rng = np.abs(z64).max()
+    e_hip, e_f32 = maxabs(zo.cpu().numpy(), z64) / rng, maxabs(z32, z64) / rng
+    print("dual path, inputs x %g: max|z| %.3g  |hip - f64| / range %.2e   |f32 oracle - f64| / range %.2e" % (scale, rng, e_hip, e_f32))
+    assert e_hip <= 3 * e_f32 + 2e-7
+    wave = weights.synth_waveform(2, 5 * 1024 + 3, seed=23) * scale
+    w64 = onp.separate(sd_default, wave.astype(np.float64), dtype=np.float64)
+    w32 = onp.separate(sd_default, wave, dtype=np.float32)
+    wo = m.separate(torch.from_numpy(wave.astype(np.float32)).cuda()).cpu().numpy()
+    rng = np.abs(w64).max()
+    e_hip, e_f32 = maxabs(wo, w64) / rng, maxabs(w32, w64) / rng
+    print("separate, inputs x %g: max|out| %.3g  |hip - f64| / range %.2e   |f32 oracle - f64| / range %.2e" % (scale, rng, e_hip, e_f32))
+    assert e_hip <= 3 * e_f32 + 2e-7
+
+
+def test_small_weight_rows_stay_accurate(sd_default):
+    """... and neither do the weights: a band whose Linear layers have rows at the 1e-5 scale (a band the training all but switched off)
+    and an LSTM with 1e-5-scale input weights must come out as accurately as the float32 oracle does, relative to the output range."""
+    from oracle import bsrnn_numpy as onp
+    from speechseparation_amd import weights
+    sd = {k: v.copy() for k, v in sd_default.items()}
+    for k in sd:
+        if k.startswith(("bandFCs_pre.7.", "bandFCs.7.", "bandFCs_back.9.", "bandFCs_back_post.9.")) and k.endswith("weight"):
+            sd[k][::2] *= 1e-5                                   # every other output row tiny
+        if k in ("lstms.1.m.rnn.weight_ih_l0", "lstms.2.m.rnn.weight_ih_l1"):
+            sd[k] *= 1e-5
+    m = make_model(sd)
+    x = weights.synth_tensor((2, 2050, 8), seed=24, scale=1.0)
+    y64 = onp.forward(sd, x, dtype=np.float64)
+    y32 = onp.forward(sd, x, dtype=np.float32)
+    y = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    rng = np.abs(y64).max()
+    e_hip, e_f32 = maxabs(y, y64) / rng, maxabs(y32, y64) / rng
+    print("tiny weight rows: max|y| %.3g  |hip - f64| / range %.2e   |f32 oracle - f64| / range %.2e" % (rng, e_hip, e_f32))
+    assert e_hip <= 3 * e_f32 + 2e-7
+    # per band: the bands fed by the tiny rows against their own range (the global range would hide them)
+    off = np.cumsum([0] + [2 * w for w in m.band_widths])
+    for b in (7, 9):
+        sl = slice(off[b], off[b + 1])
+        r_b = np.abs(y64[:, sl]).max()
+        print("  band %d: range %.3g  |hip - f64| / band range %.2e  |f32 - f64| / band range %.2e" % (
+            b, r_b, maxabs(y[:, sl], y64[:, sl]) / r_b, maxabs(y32[:, sl], y64[:, sl]) / r_b))
+        assert maxabs(y[:, sl], y64[:, sl]) / r_b <= 3 * maxabs(y32[:, sl], y64[:, sl]) / r_b + 1e-6
+
+
 def test_large_inputs_stay_accurate_and_out_of_range_is_exact(sd_default):
     """The fp16x2 matrix path represents operands up to 65504.  Inside that range accuracy must not depend on the magnitude
     (a spectrum scaled to |x| ~ 1e3, the ceiling for audio in [-1, 1]).  Beyond it the reference's forward still returns
