@@ -363,15 +363,23 @@ def main():
         model.separate(wave, out=out)
     # timed region: only the dominant kernel family (the grouped fp32-MFMA GEMM launches of the
     # two per-band MLP chains) is bracketed with HIP events, on the launch stream
-    model.set_profiling(DOMINANT, device)
+    # (every SAMPLE-th step of the timed region carries the brackets: an event pair costs the stream ~2.5 us, tools/bracket_cost.py;
+    #  the durations are averaged over the bracketed launches only)
+    SAMPLE = 4
+    model.set_profiling(False, device)
     model.stage_times(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i % SAMPLE == 0:
+            model.set_profiling(DOMINANT, device)
+        elif i % SAMPLE == 1:
+            model.set_profiling(False, device)
         model.separate(wave, out=out)
     barrier()
     elapsed = time.perf_counter() - t0
     dom_stages = model.stage_times(reset=True)
+    n_sampled = (args.steps + SAMPLE - 1) // SAMPLE
     # per-stage table: a few extra steps with every stage bracketed (not part of `value`)
     model.set_profiling(True, device)
     n_extra = 5
@@ -380,6 +388,41 @@ def main():
     stages = model.stage_times(reset=True)
     model.set_profiling(False, device)
     model.sync()                                  # raises if any step of the run left the fp16x2 range
+    # With the dual path overlapped (the default for this workload) the mask chain is LAUNCHED beside the second time-axis launch and
+    # its workgroups wait for their frames: its launch duration then contains that wait.  The same kernels one after the other
+    # (a second context under BSRNN_OVERLAP=0, same weights and input): what the kernels take when nothing runs beside them.
+    alone = None
+    if model.overlap_state(device) == 1:
+        keep = os.environ.get("BSRNN_OVERLAP")
+        os.environ["BSRNN_OVERLAP"] = "0"
+        try:
+            m2, _ = build_model(device)
+            m2.set_range_policy("deferred")
+            for _ in range(8):
+                m2.separate(wave, out=out)
+            m2.set_profiling(DOMINANT, device)
+            m2.stage_times(reset=True)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            n_alone = 20
+            for _ in range(n_alone):
+                m2.separate(wave, out=out)
+            torch.cuda.synchronize()
+            alone_ms = 1e3 * (time.perf_counter() - ta) / n_alone
+            st2 = m2.stage_times(reset=True)
+            m2.set_profiling(True, device)        # ... and the per-stage table of that flow (every stage bracketed)
+            for _ in range(n_extra):
+                m2.separate(wave, out=out)
+            stages_alone = m2.stage_times(reset=True)
+            m2.set_profiling(False, device)
+            m2.sync()
+            alone = {"ms_per_step": round(alone_ms, 4), "stages_ms": {k: round(st2[k][0] / n_alone, 4) for k in DOMINANT}, "all": stages_alone}
+            del m2
+        finally:
+            if keep is None:
+                os.environ.pop("BSRNN_OVERLAP", None)
+            else:
+                os.environ["BSRNN_OVERLAP"] = keep
     # the reference's own operator on the same batch: BSRNN.forward on [R, 2050, T] (two layout transposes that `separate`
     # does not pay, no STFT / iSTFT) - a report item beside `value`
     xspec = model.stft(wave)
@@ -423,6 +466,10 @@ def main():
     if rank == 0:
         rf = (hi - lo) * T                                   # row-frames one launch processes on this GPU
         macs = exact_macs(spec.generate_bandsplits()[0])
+        stages_overlapped = None
+        if alone is not None:                     # the per-stage table describes the kernels: taken from the flow without overlap
+            stages_overlapped = {k: round(ms / n_extra, 4) for k, (ms, n) in stages.items() if n}
+            stages = alone["all"]
         per_step = {k: (ms / n_extra) for k, (ms, n) in stages.items() if n}
         fam = {}
         for name, ms in per_step.items():
@@ -431,14 +478,14 @@ def main():
                 fam[name]["tflops"] = round(2 * macs[name] * rf / (ms * 1e-3) / 1e12, 2)
         # dominant kernel = gemm_f32_kernel; its 10 launches per step inside the two MLP chains are
         # what the timed-region events bracket (5 launches per bracket)
-        dom_ms_step = sum(dom_stages[k][0] for k in DOMINANT) / args.steps
+        dom_ms_step = sum(dom_stages[k][0] for k in DOMINANT) / n_sampled
         dom_flop_step = 2 * sum(macs[k] for k in DOMINANT) * rf
         from speechseparation_amd import _native
         cmode = _native.compute_mode()
         flow = mlp_flow(cmode["gemm"])
         # launches of the dominant family per step: every bracket of the two MLP stages holds 1 (fused) or 5 (per-layer)
         # launches, and bsrnn_separate runs the batch as `blocks` concurrent row blocks (2 from 64 rows on), each with its own
-        n_brackets = sum(dom_stages[k][1] for k in DOMINANT) / float(args.steps)
+        n_brackets = sum(dom_stages[k][1] for k in DOMINANT) / float(n_sampled)
         blocks = max(1, int(round(n_brackets / 2.0)))
         n_launch = int(round(n_brackets)) * (1 if flow == "fused" else 5)
         kname, peak, basis = GEMM_ROOF[cmode["gemm"]]
@@ -460,7 +507,16 @@ def main():
                                  "frac_of_hbm_peak": round(act_bytes * rf / (dom_ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                  "note": "the same launches against HBM: activations in + out per launch, weights excluded"},
                     "note": "achieved = algorithmic flops (2 x MACs of the Linear layers x row-frames, fp32 semantics) / launch time; "
-                            "HIP events on the launch stream over the timed region"}
+                            "HIP events on the launch stream inside the timed region, on every %d-th of its steps (%d launches timed)" % (SAMPLE, n_sampled * n_launch)}
+        roofline["dual_path_flow"] = {0: "one launch after the other (BSRNN_OVERLAP=0)", 1: "overlapped: second band block beside the first time-axis launch, mask chain beside the second (auxiliary stream, per-workgroup waits)",
+                                      2: "overlap switched off after a consumer's wait expired"}.get(model.overlap_state(device), "?")
+        roofline["per_stage_ms"] = {k: round(dom_stages[k][0] / n_sampled, 4) for k in DOMINANT}
+        if alone is not None:
+            a_ms = sum(alone["stages_ms"].values())
+            roofline["kernels_alone"] = {"ms_per_step_of_that_flow": alone["ms_per_step"], "stages_ms": alone["stages_ms"],
+                                         "achieved": round(dom_flop_step / (a_ms * 1e-3) / 1e12, 2), "frac": round(dom_flop_step / (a_ms * 1e-3) / 1e12 / peak, 4),
+                                         "note": "the same two launches with nothing beside them (second context, BSRNN_OVERLAP=0, 20 bracketed steps): in the overlapped flow "
+                                                 "the mask chain's launch starts beside the second time-axis launch and its duration contains its workgroups' waits for their frames"}
         dp_ms = sum(per_step.get(k, 0.0) for k in ("band_lstm", "band_fc", "time_lstm", "time_fc"))
         dp_gbs = BYTES_DUAL_PATH * rf / (dp_ms * 1e-3) / 1e9 if dp_ms else 0.0
         dual = {"bound": "hbm", "achieved": round(dp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -490,6 +546,10 @@ def main():
                                         "f16/bf16 matrix cores unless 'f32' (error at fp32 rounding level, DESIGN.md)"),
             "roofline": roofline, "roofline_dual_path": dual, "stages": fam,
         }
+        if stages_overlapped is not None:
+            line["stages_note"] = ("`stages` and `roofline_dual_path` are the launches one after the other (second context, BSRNN_OVERLAP=0: %.4f ms per step); "
+                                   "in the overlapped flow that `value` measures a consumer launch's bracket contains its waits" % alone["ms_per_step"])
+            line["stages_overlapped_flow_ms"] = stages_overlapped
         if f32_rec is not None:
             line["exact_f32"] = f32_rec
         if train_rec is not None:

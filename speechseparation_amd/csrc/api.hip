@@ -1226,8 +1226,13 @@ int bsrnn_commit_params(bsrnn_ctx* c)
             const bool no48 = getenv("BSRNN_CHAIN_NO48") != nullptr;
             const bool try48 = RT == 1 && GR == 1 && !no48;
             const bool try80 = RT == 2 && GR == 1 && !no48 && !getenv("BSRNN_CHAIN_NO80");
+            // ... and the other bands of the 64-row class (the 514-wide band: 33 feature tiles of 16, ragged) on FOUR row tiles of 16: the same 64
+            // rows, but two feature tiles' fragments per k-step and four k-steps in flight per wave (128 KB per CU instead of the 64 KB the
+            // two-row-tile 32 x 32 body has registers for, which held its K loops at 48 GB/s per CU against the 70 the fill path gives:
+            // profiles/r03_chain_trace.txt); BSRNN_CHAIN_NO64=1 keeps them on the 32 x 32 geometry
+            bool try64 = false;
             if (try48 || try80) {
-                const int rt16 = try48 ? 3 : 5, ctr = try48 ? 6 : 3;
+                int rt16 = try48 ? 3 : 5, ctr = try48 ? 6 : 3;
                 int u48 = 0, maxft = 0, nb48 = 0;
                 bool whole = true;                                   // every layer's width a multiple of 16 (no ragged tile of 16)
                 for (int l = 0; l < CHAIN_LAYERS; ++l) {
@@ -1237,7 +1242,10 @@ int bsrnn_commit_params(bsrnn_ctx* c)
                     maxft = imax(maxft, FT); nb48 += 16 * FT;
                     whole = whole && ld[l].N % 16 == 0;
                 }
-                if (2 * u48 * (16 * rt16) * 16 <= CHAIN_LDS_EX && maxft <= 8 * ctr && nb48 * 4 <= CHAIN_LDS_BIAS && (try48 || (whole && maxft % 8 == 0))) {
+                if (try80 && !(whole && maxft % 8 == 0 && maxft <= 8 * ctr && 2 * u48 * (16 * rt16) * 16 <= CHAIN_LDS_EX) && !getenv("BSRNN_CHAIN_NO64")) {
+                    try64 = true; rt16 = 4; ctr = 5;
+                }
+                if (2 * u48 * (16 * rt16) * 16 <= CHAIN_LDS_EX && maxft <= 8 * ctr && nb48 * 4 <= CHAIN_LDS_BIAS && (try48 || try64 || (whole && maxft % 8 == 0))) {
                     g48 = true; RT = rt16; GR = 1; units = u48; nbias = 0; cost = 0;
                     for (int l = 0; l < CHAIN_LAYERS; ++l) {
                         d.L[l].K16 = (ld[l].Kd + 31) / 32; d.L[l].NTL = (ld[l].N + 15) / 16;

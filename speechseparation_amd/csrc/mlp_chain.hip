@@ -66,6 +66,12 @@ constexpr int PD = CHAIN_PD;
 #ifndef CHAIN_PRIO
 #define CHAIN_PRIO 0
 #endif
+#ifndef CHAIN_PD64
+#define CHAIN_PD64 3               // prefetch depth of the 64-row geometry on 16 x 16 tiles (four row tiles)
+#endif
+#ifndef CHAIN_TP64
+#define CHAIN_TP64 2               // ... and its feature tiles per pass over K
+#endif
 #ifndef CHAIN_PD48
 #define CHAIN_PD48 4               // prefetch depth of the 48-row geometry (its k-steps carry two tiles' fragments)
 #endif
@@ -526,7 +532,9 @@ __device__ __forceinline__ void chain_body(const ChainLaunch& g, const ChainDesc
 // RT row tiles of 16 (48 rows: the 768-wide band; 80 rows: bands whose image leaves room for five - the 384-wide band, 24 feature
 // tiles = three per wave where the 32 x 32 geometry had twelve tiles for eight waves and 64 rows per weight fragment), CTR = feature
 // tiles per wave the held-tile registers are sized for, PDR = k-steps of weight fragments in flight.
-template <int CHAIN, int TERMS, int RT = 3, int CTR = 6, int PDR = CHAIN_PD48, int TP = 2>
+// ZPAD: the band's widths are not multiples of 16 / 32 (the 514-wide band on four row tiles): the k-units of the image that no layer's
+// output covers but a later layer's K loop reads (against zero weights) are zeroed once - uninitialised LDS may hold NaN patterns.
+template <int CHAIN, int TERMS, int RT = 3, int CTR = 6, int PDR = CHAIN_PD48, int TP = 2, bool ZPAD = false>
 __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDesc* const dp, const int row0, char* const smem)
 {
     constexpr int NPL = (TERMS == 1 || TERMS == -1) ? 1 : 2;
@@ -617,6 +625,13 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
                     *reinterpret_cast<h4*>(d) = p0;
                     if (NPL == 2) *reinterpret_cast<h4*>(d + plane) = p1;
                 }
+        }
+        if (ZPAD) {
+            const int tail = (dp->plane_units - U0) * UB;                     // bytes behind the staged input, per piece
+            for (int o = tid * 16; o < tail; o += 512 * 16) {
+                *reinterpret_cast<uint4*>(smem + U0 * UB + o) = make_uint4(0, 0, 0, 0);
+                if (NPL == 2) *reinterpret_cast<uint4*>(smem + plane + U0 * UB + o) = make_uint4(0, 0, 0, 0);
+            }
         }
     }
     __syncthreads();
@@ -818,7 +833,8 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
     // geometry of the workgroup (wave-uniform): 48 rows on 16 x 16 tiles, or rows = 32 RT GR on 32 x 32 tiles
     const int RT = dp->RT, GR = 8 / dp->NW;
 #ifdef CHAIN_ONLY_BODY            // measurement only: compile ONE geometry (register / scratch use per body: tools/kernel_resources.py)
-    if (CHAIN_ONLY_BODY == 0) chain_body48<CHAIN, TERMS>(g, dp, row0, smem);
+    if (CHAIN_ONLY_BODY == 6) chain_body48<CHAIN, TERMS, 4, 5, CHAIN_PD64, CHAIN_TP64, true>(g, dp, row0, smem);
+    else if (CHAIN_ONLY_BODY == 0) chain_body48<CHAIN, TERMS>(g, dp, row0, smem);
     else if (CHAIN_ONLY_BODY == 1) chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem);
     else if (CHAIN_ONLY_BODY == 2) chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem);
     else if (CHAIN_ONLY_BODY == 3) chain_body<CHAIN, TERMS, 2, 1>(g, dp, row0, smem);
@@ -831,6 +847,7 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
     //  and keeps values of the later ones - the thread index, for one - alive through the earlier ones' loops: spills at 256 VGPRs)
     if (RT == 3) { chain_body48<CHAIN, TERMS>(g, dp, row0, smem); return; }
     if (RT == 5) { chain_body48<CHAIN, TERMS, 5, 3, 2, (CHAIN == CHAIN_SPLIT ? 1 : 2)>(g, dp, row0, smem); return; }
+    if (RT == 4) { chain_body48<CHAIN, TERMS, 4, 5, CHAIN_PD64, CHAIN_TP64, true>(g, dp, row0, smem); return; }
     if (GR == 8) { chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem); return; }
     if (RT == 1 && GR == 1) { chain_body<CHAIN, TERMS, 1, 1>(g, dp, row0, smem); return; }
     if (RT == 2 && GR == 1) { chain_body<CHAIN, TERMS, 2, 1>(g, dp, row0, smem); return; }

@@ -66,6 +66,7 @@ int main(int argc, char** argv)
         if (getenv("CHAIN_GEOM")) sscanf(getenv("CHAIN_GEOM"), "%d,%d", &RT, &GR);      // override (must fit the LDS)
         const bool try48 = RT == 1 && GR == 1 && !getenv("BSRNN_CHAIN_NO48");
         bool try80 = RT == 2 && GR == 1 && !getenv("BSRNN_CHAIN_NO48") && !getenv("BSRNN_CHAIN_NO80");
+        bool try64 = false;
         if (try80) {                                    // as api.hip: five row tiles of 16 where they fit and the tiles of 16 are 3 x 8 at most
             int u = 0, maxft = 0; bool whole = true;
             for (int l = 0; l < 5; ++l) {
@@ -74,11 +75,13 @@ int main(int argc, char** argv)
                 if (l < 4) u = std::max(u, 2 * ((N + 15) / 16));
                 maxft = std::max(maxft, (N + 15) / 16); whole = whole && N % 16 == 0;
             }
+            const bool was80 = try80;
             try80 = 2 * u * 80 * 16 <= CHAIN_LDS_EX && maxft <= 24 && whole && maxft % 8 == 0;
+            try64 = was80 && !try80 && !getenv("BSRNN_CHAIN_NO64") && 2 * u * 64 * 16 <= CHAIN_LDS_EX && maxft <= 40;      // as api.hip: four row tiles of 16
         }
-        const bool g48 = try48 || try80;
+        const bool g48 = try48 || try80 || try64;
         if (g48) {
-            RT = try48 ? 3 : 5; GR = 1; units = 0; nbias = 0;
+            RT = try48 ? 3 : (try64 ? 4 : 5); GR = 1; units = 0; nbias = 0;
             for (int l = 0; l < 5; ++l) {
                 const int N = chain ? dims_m[l][0] : dims_s[l][0], Kd = chain ? dims_m[l][1] : dims_s[l][1];
                 d.L[l].K16 = (Kd + 31) / 32; d.L[l].NTL = (N + 15) / 16; d.L[l].bias_off = nbias; nbias += 16 * d.L[l].NTL;

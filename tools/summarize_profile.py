@@ -26,6 +26,7 @@ def short(name):
 
 def main():
     tag, prof, fetch, write, tcc, sq = sys.argv[1:7]
+    extra = sys.argv[7:10]          # optional: the L1 -> L2 request pass, the LDS pass, the wave-cycle pass (tools/profile_round.sh)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out_dir, exist_ok=True)
     stats = rows(prof, "*_kernel_stats.csv")
@@ -65,6 +66,27 @@ def main():
         lines.append("| %s | %.1f | %.1f | %.1f | %s | %s |" % (
             k, dur[k], fe, wr, "%.0f" % (100 * hit / (hit + miss)) if hit + miss else "-",
             "%.0f" % (100 * busy / 1024 / (gui / 8)) if gui else "-"))
+    if len(extra) == 3:
+        l_, d_, v_ = per_dispatch(extra[0]), per_dispatch(extra[1]), per_dispatch(extra[2])
+        lines += ["", "What bounds the kernels (separate PMC passes; per launch).  L1 -> L2 read MB = TCP_TCC_READ_REQ x 64 B (requests of 64 B;"
+                  " a 128 B line read = 2), GB/s per CU = that / avg us / 256 CUs; L1 stalled on L2 = TCP_PENDING_STALL_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs);"
+                  " LDS: bank-conflict cycles / LDS-active cycles, and the share of wave cycles spent waiting on LDS instructions; waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES.", "",
+                  "| kernel | L1->L2 read MB | L1->L2 write MB | L2->CU GB/s per CU | L1 stalled on L2 % | LDS conflict % of LDS cycles | wave cycles waiting on LDS % | wave cycles waiting (any) % |",
+                  "|---|---|---|---|---|---|---|---|"]
+        for k in sorted(dur, key=lambda x: -dur[x]):
+            if "rocclr" in k or k not in l_:
+                continue
+            rd = l_[k].get("TCP_TCC_READ_REQ_sum", 0) * 64 / 1e6
+            wrq = l_[k].get("TCP_TCC_WRITE_REQ_sum", 0) * 64 / 1e6
+            gui = s_.get(k, {}).get("GRBM_GUI_ACTIVE", 0)
+            stall = l_[k].get("TCP_PENDING_STALL_CYCLES_sum", 0)
+            conf, act = d_.get(k, {}).get("SQ_LDS_BANK_CONFLICT", 0), d_.get(k, {}).get("SQ_LDS_IDX_ACTIVE", 0)
+            wlds = d_.get(k, {}).get("SQ_WAIT_INST_LDS", 0)
+            wc, wany = v_.get(k, {}).get("SQ_WAVE_CYCLES", 0), v_.get(k, {}).get("SQ_WAIT_ANY", 0)
+            lines.append("| %s | %.0f | %.0f | %.1f | %s | %s | %s | %s |" % (
+                k, rd, wrq, rd * 1e6 / (dur[k] * 1e-6) / 256 / 1e9,
+                "%.0f" % (100 * stall / (gui * 256)) if gui else "-", "%.1f" % (100 * conf / act) if act else "-",
+                "%.0f" % (100 * wlds / wc) if wc else "-", "%.0f" % (100 * wany / wc) if wc else "-"))
     open(os.path.join(out_dir, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
     import json
     traffic = {k: {"fetched_bytes": 2 * f_.get(k, {}).get("FETCH_SIZE", 0) * 1024, "written_bytes": w_.get(k, {}).get("WRITE_SIZE", 0) * 1024,
