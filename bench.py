@@ -530,6 +530,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
             "ms_per_step": round(ms_per_step, 4), "per_rank_ms": [round(v, 4) for v in per_rank_ms],
             "per_rank_ms_min_max": [round(min(per_rank_ms), 4), round(max(per_rank_ms), 4)],
+            "per_rank_ms_max_over_min": round(max(per_rank_ms) / min(per_rank_ms), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "range_guard": "deferred in the timed loop (explicit opt-out of the default per-call synchronise-and-check, include/bsrnn_hip.h); "
                            "guard word read after the run: clean.  The same call under the default policy: %.4f ms per call" % exact_ms,

@@ -113,6 +113,8 @@ struct bsrnn_ctx {
     size_t train_ws_floats = 0;
     std::vector<float*> train_ws_retired;   // outgrown scratch buffers: a captured training graph (train.GraphedTrainStep) may still point at
                                             // them, so they live until the context goes (growth is geometric: at most ~4x the final size in all)
+    std::vector<void*> retired;             // likewise the outgrown workspaces / tap buffers / progress words (bsrnn_stft, _istft, _istft_backward and
+                                            // every model entry point put workspace addresses into captured kernel nodes)
     int* d_colmap = nullptr;
     FftTables tb;
 
@@ -319,8 +321,11 @@ void lstm_cat(const bsrnn_ctx* c, int j, int layer, const char* sfx, int n_in, s
 int ensure_ws(bsrnn_ctx* c, size_t rows)
 {
     if (rows <= c->cap_rows) return 0;
-    HIP_TRY(hipDeviceSynchronize());
-    if (c->d_ws) { HIP_TRY(hipFree(c->d_ws)); c->d_ws = nullptr; c->cap_rows = 0; }
+    // Grow-only, geometrically, and the outgrown buffer is RETIRED, not freed: a hipGraph captured by the caller (train.GraphedTrainStep keeps
+    // one per clip length; a user's torch.cuda.graph around forward) holds workspace addresses in its kernel nodes, and work of the previous
+    // call may still be running in it.  It stays valid scratch for whoever knows it; everything new uses the new one (streaming graphs of
+    // this library re-capture: generation counter).  At most ~3x the final size in all, released with the context.
+    if (c->cap_rows) rows = std::max(rows, c->cap_rows + c->cap_rows / 2);
     const size_t KH = (size_t)c->K * HID;
     auto seg = [](size_t n) { return (n + 63) & ~size_t(63); };
     const size_t sizes[11] = {seg(rows * c->LDP), seg(rows * c->LDP), seg(rows * c->LDA), seg(rows * c->LDA), seg(rows * c->LDP),
@@ -328,11 +333,14 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
                               seg(rows / 8 + 2 * MAX_PARTS + 64)};
     size_t total = 0;
     for (size_t s : sizes) total += s;
+    float* fresh = nullptr;
     ++g_dbg[DBG_ALLOC];
-    HIP_TRY(hipMalloc((void**)&c->d_ws, total * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&fresh, total * sizeof(float)));
     // pad columns (band segments are 16-byte aligned, rows padded) are read as K-padding by the GEMM and are
     // never written afterwards: they must be finite, so the whole workspace starts at zero
-    HIP_TRY(hipMemset(c->d_ws, 0, total * sizeof(float)));
+    HIP_TRY(hipMemset(fresh, 0, total * sizeof(float)));
+    if (c->d_ws) c->retired.push_back(c->d_ws);
+    c->d_ws = fresh;
     float* p = c->d_ws;
     float** dst[10] = {&c->Xf, &c->Yf, &c->A1, &c->A2, &c->P, &c->Z0, &c->Z1, &c->HB0, &c->HB1, &c->H1};
     for (int i = 0; i < 10; ++i) { *dst[i] = p; p += sizes[i]; }
@@ -344,10 +352,12 @@ int ensure_ws(bsrnn_ctx* c, size_t rows)
 int ensure_tap(bsrnn_ctx* c, size_t rows)
 {
     if (rows <= c->tap_rows) return 0;
-    HIP_TRY(hipDeviceSynchronize());
-    if (c->d_tap) { HIP_TRY(hipFree(c->d_tap)); c->d_tap = nullptr; }
+    if (c->tap_rows) rows = std::max(rows, c->tap_rows + c->tap_rows / 2);
+    float* fresh = nullptr;
     ++g_dbg[DBG_ALLOC];
-    HIP_TRY(hipMalloc((void**)&c->d_tap, rows * c->LDP * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&fresh, rows * c->LDP * sizeof(float)));
+    if (c->d_tap) c->retired.push_back(c->d_tap);          // (retired like the workspace, see ensure_ws)
+    c->d_tap = fresh;
     c->tap_rows = rows;
     ++c->gen;
     return 0;
@@ -517,7 +527,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
             OvlConsumer oc = {nullptr, 0, 0, nullptr};
             const bool cons = p.ovl && blk && (p.ovl_mode & 1);
             if (cons)                             // beside the first time-axis launch: tiles in the order their frames leave it
-                oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 4096 : OVL_SPIN_LIMIT, p.ovl->band_order};
+                oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT, p.ovl->band_order};
             launch_band_pair(zi, p.HB0, p.HB1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1], M, K, c->d_range, s,
                              parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr,
                              p.ovl && p.ovl_zero_blk == blk ? c->d_ovl : nullptr, 2 * c->ovl_stride);
@@ -576,7 +586,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
             if (p.ovl && (p.ovl_mode & 2)) {      // beside the second time-axis launch: the earliest-ready heavy workgroups first
                 g.tasks = p.ovl->mask_tasks; g.n_tasks = p.ovl->n_mask;
                 g.ovl_prog = c->d_ovl + c->ovl_stride + OVL_HEAD; g.ovl_T = p.T; g.ovl_K = K;
-                g.ovl_spin = c->overlap_sabotage ? 4096 : OVL_SPIN_LIMIT;
+                g.ovl_spin = c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT;
             }
             launch_mlp_chain(g, CHAIN_MASK, s);
             break;
@@ -622,8 +632,7 @@ int ensure_ovl(bsrnn_ctx* c, int C, int T)
     const int M = C * T, K = c->K, nwg = (C * K + 3) / 4;
     const int stride = OVL_HEAD + ((nwg + 15) & ~15);
     if (stride > c->ovl_stride) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (c->d_ovl) { HIP_TRY(hipFree(c->d_ovl)); c->d_ovl = nullptr; }
+        if (c->d_ovl) { c->retired.push_back(c->d_ovl); c->d_ovl = nullptr; }      // (retired like the workspace, see ensure_ws)
         ++g_dbg[DBG_ALLOC];
         HIP_TRY(hipMalloc((void**)&c->d_ovl, (size_t)2 * stride * sizeof(int)));
         HIP_TRY(hipMemset(c->d_ovl, 0, (size_t)2 * stride * sizeof(int)));
@@ -720,9 +729,14 @@ void run_overlapped(bsrnn_ctx* c, Part p, const bsrnn_ctx::OvlTable* tb, int fir
     }
     for (int st = MS_MASK + 1; st <= last; ++st) run_stage(c, p, st);
 }
-static const bsrnn_ctx::OvlTable* ovl_table(const bsrnn_ctx* c, int C, int T)
+// (a call that is being captured into a caller's hipGraph runs launch after launch: a graph is replayed by whoever owns it, possibly beside
+//  other replays of itself on other streams, and the progress words belong to ONE call in flight per context)
+static const bsrnn_ctx::OvlTable* ovl_table(const bsrnn_ctx* c, int C, int T, hipStream_t s)
 {
     if (!overlap_wanted(c, C, T) || !c->d_ovl) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }      // (the legacy default stream cannot be captured)
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
     auto it = c->ovl_tables.find(std::make_pair(C, T));
     return it == c->ovl_tables.end() ? nullptr : &it->second;
 }
@@ -737,7 +751,7 @@ int run_model(bsrnn_ctx* c, const float* Xf, float* Yf, float* tap, int C, int T
     p.Xf = Xf; p.Yf = Yf; p.tap = tap;
     p.state_in = state_in; p.state_out = state_out;
     p.state_slab = (size_t)2 * 2 * C * c->K * HID;     // one Time block's (h,c) x 2 layers
-    const bsrnn_ctx::OvlTable* tb = c->small_rows ? nullptr : ovl_table(c, C, T);
+    const bsrnn_ctx::OvlTable* tb = c->small_rows ? nullptr : ovl_table(c, C, T, s);
     if (tb) run_overlapped(c, p, tb, MS_BANDSPLIT, MS_MASK);
     else
     for (int st = MS_BANDSPLIT; st <= MS_MASK; ++st) run_stage(c, p, st);
@@ -972,6 +986,7 @@ static void destroy_now(bsrnn_ctx* c)
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_train_ws) (void)hipFree(c->d_train_ws);
     for (float* p : c->train_ws_retired) (void)hipFree(p);
+    for (void* p : c->retired) (void)hipFree(p);
     if (c->d_colmap) (void)hipFree(c->d_colmap);
     if (c->h_range) (void)hipHostFree(c->h_range);
     delete c;
@@ -1931,7 +1946,7 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
             HIP_TRY(hipEventRecord(c->ev_fork, s));
             for (int j = 0; j < parts; ++j) HIP_TRY(hipStreamWaitEvent(c->aux[j], c->ev_fork, 0));
         }
-        const bsrnn_ctx::OvlTable* tb = parts == 1 ? ovl_table(c, R, T) : nullptr;
+        const bsrnn_ctx::OvlTable* tb = parts == 1 ? ovl_table(c, R, T, s) : nullptr;
         if (tb) run_overlapped(c, pt[0], tb, MS_STFT, MS_ISTFT);      // the dual path overlapped on the context's auxiliary stream
         const int lag = c->part_lag;
         for (int step = 0; !tb && step < MS_COUNT + lag * (parts - 1); ++step)

@@ -130,8 +130,10 @@ void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 //       flag value 5: api.hip runs the call again launch after launch and stops overlapping), never computed with.
 // All words are zeroed in stream order before the producers of a call start; nothing travels by value that changes from call to call.
 struct OvlProducer { int* resident; int* prog; };
-struct OvlConsumer { const int* prog; int T; int spin_limit; const int* order; };   // order (band launch): dispatch ordinal -> tile of 16 sequences, by the time its frames are ready
-constexpr int OVL_SPIN_LIMIT = 1 << 22;        // polls (each followed by s_sleep) before a wait gives up: seconds
+struct OvlConsumer { const int* prog; int T; int spin_limit; const int* order; };   // spin_limit: 100 MHz ticks a wait may last   // order (band launch): dispatch ordinal -> tile of 16 sequences, by the time its frames are ready
+constexpr int OVL_SPIN_LIMIT = 20000000;       // 100 MHz ticks (s_memrealtime) before a wait gives up: 200 ms - a healthy wait lasts as long as a
+                                               // time-axis launch (0.1 ... a few ms); under a tool that serialises kernels (rocprofv3 --pmc) the
+                                               // producer never runs beside the consumer: the call falls back after this long, once per context
 void launch_ovl_gate(const int* resident, int target, int* range_flag, int spin_limit, hipStream_t stream);
 #if defined(__HIPCC__)
 // frame rows m_first .. m_last (m = batch row * T + frame) of bands k_first .. k_last: wait until every time-axis workgroup that owns one
@@ -141,14 +143,14 @@ __device__ __forceinline__ bool ovl_wait_rows(const int* prog, int m_first, int 
     typedef const int __attribute__((address_space(1)))* gci;
     const gci pg = (gci)prog;
     const int r_a = m_first / T, r_b = m_last / T;
-    int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (int r = r_a; r <= r_b; ++r) {
         const int t_last = r < r_b ? T - 1 : m_last - r * T;
         const int need = (t_last >> 2) + 1;
         for (int wg = (r * K + k_first) >> 2; wg <= (r * K + k_last) >> 2; ++wg)
             while (__hip_atomic_load(pg + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > limit) return false;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) return false;
             }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // this CU's L1 holds nothing older than the poll

@@ -1371,12 +1371,15 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
             // order and drains all its older stores with it, so f + 1 published groups mean groups 0 .. f are complete whichever wave
             // published them).  Called one group late, where the wave waits for its residual loads anyway: no extra stall on H1.
             const bool pub = FUSE && PART && ovl_prog != nullptr;       // (only the parts flow overlaps: api.hip)
+            // The consumers work in tiles of 16 frames and more, so progress is published every FOURTH group (and at the end): one drain per 16
+            // steps instead of one per 4 keeps H1's stalls on its write-through stores off the chain (each drain covers all the wave's older stores).
             auto publish = [&](int f) {
+                if ((f & 3) != 3 && f != G - 1) return;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 int old = 0;
-                if (lane == 0) old = __hip_atomic_fetch_add(&outc[f & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) old = __hip_atomic_fetch_add(&outc[(f >> 2) & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 old = __builtin_amdgcn_readfirstlane(old);
-                if ((old & 3) == 3 && lane == 0) __hip_atomic_fetch_add(ovl_prog + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((old & 3) == 3 && lane == 0) __hip_atomic_fetch_add(ovl_prog + blockIdx.x, (f & 3) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
             auto fc_finish = [&](int f) {
                 if (pub && f >= 1) publish(f - 1);
@@ -1791,10 +1794,10 @@ __global__ void ovl_gate_kernel(const int* resident, int target, int* range_flag
 {
     if (threadIdx.x) return;
     typedef const int __attribute__((address_space(1)))* gci;
-    int spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load((gci)resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(32);
-        if (++spins > limit) { if (range_flag) *range_flag = 5; return; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) { if (range_flag) *range_flag = 5; return; }
     }
 }
 void launch_ovl_gate(const int* resident, int target, int* range_flag, int spin_limit, hipStream_t stream)

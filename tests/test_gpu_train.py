@@ -554,3 +554,38 @@ def test_training_gradients_on_the_41_band_table():
         n += 1
     print("41-band table: %d parameter tensors, worst relative gradient error %.2e (%s)" % (n, worst[1], worst[0]))
     assert n > 800 and worst[1] < 1e-3, worst
+
+
+def test_graphs_of_two_clip_lengths_survive_a_growing_scratch():
+    """train.py --graph keeps one captured iteration per clip length.  The library's training scratch is grow-only: the eager warm-up of a
+    LONGER clip outgrows it after the first graph has been captured with the old buffer's address in its kernel nodes.  The old buffer must stay
+    valid (it is retired, not freed: csrc/api.hip::train_scratch): replaying the first graph after the second one's warm-up and capture
+    gives the same losses as the Python-driven loop on the same sequence of clips."""
+    from speechseparation_amd import train, weights
+    from speechseparation_amd.bsrnn import BSRNN
+    sd = weights.synth_state_dict(None, seed=0)
+    n_a, n_b = 4 * 1024, 9 * 1024                                            # ascending: the second length more than 25 % larger
+    mk = lambda n, s: (torch.from_numpy(weights.synth_waveform(2, n, seed=s)).cuda(), torch.from_numpy(weights.synth_waveform(2, n, seed=s + 50)).cuda())
+    seq = [("a", mk(n_a, 1)), ("a", mk(n_a, 2)), ("a", mk(n_a, 3)), ("b", mk(n_b, 4)), ("b", mk(n_b, 5)), ("b", mk(n_b, 6)),
+           ("a", mk(n_a, 7)), ("b", mk(n_b, 8)), ("a", mk(n_a, 9))]
+
+    def fresh(capturable):
+        m = BSRNN().train()
+        m.load_state_dict({k: torch.from_numpy(np.array(a, copy=True)) for k, a in sd.items()})
+        m = m.to("cuda:0")
+        return m, train.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-2, capturable=capturable)
+
+    m1, o1 = fresh(False)
+    eager = [float(train.train_step(m1, o1, *clip)) for _, clip in seq]
+    m2, o2 = fresh(True)
+    steps = {"a": train.GraphedTrainStep(m2, o2, 2, n_a, warmup=1), "b": train.GraphedTrainStep(m2, o2, 2, n_b, warmup=1)}
+    graphed = [float(steps[k](*clip)) for k, clip in seq]
+    assert steps["a"].graph is not None and steps["b"].graph is not None
+    print("eager  ", eager)
+    print("graphed", graphed)
+    for a, b in zip(graphed, eager):
+        assert np.isfinite(a) and abs(a - b) <= 5e-6 * abs(b), (graphed, eager)
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    worst = max((float((p1[k] - p2[k]).abs().max()), k) for k in p1 if p1[k].numel())
+    print("largest parameter difference eager vs two graphs after nine steps: %.2e (%s)" % worst)
+    assert worst[0] < 5e-6
