@@ -280,9 +280,9 @@ int  bsrnn_evaluate(bsrnn_ctx* ctx, const float* mix_dev, const float* speech_de
 /* ---- streaming (infer-streaming.py:84-147; speech-ladspa-onnx.cpp:171-267) -------------
  * A bsrnn_stream owns, on the device, the sliding 2048-sample analysis buffer, the LSTM
  * state [4,2,C*K,64] and the previous synthesis frame for C rows.
- * bsrnn_stream_create does ALL first-use work (allocations, loading every kernel, capturing and instantiating the step's
- * hipGraphs: two throw-away steps on zero input, carry zeroed again afterwards), so that the first bsrnn_stream_step* call
- * costs what every later one costs.
+ * bsrnn_stream_create does ALL first-use work (allocations, loading every kernel, and - with BSRNN_STREAM_GRAPH=1 - capturing
+ * and instantiating the step's hipGraphs: two throw-away steps on zero input, carry zeroed again afterwards), so that the first
+ * bsrnn_stream_step* call costs what every later one costs.
  * bsrnn_stream_step: chunk_dev [C, 1024] -> out_dev [C, 1024] (delayed by one chunk):
  *     rfft(buf*hann) -> forward_recurrent -> irfft -> 2-slot overlap-add / sum(window).
  * bsrnn_stream_step_host: same with host buffers, synchronous (used by the LADSPA plugin);

@@ -2099,7 +2099,11 @@ int bsrnn_stream_create(bsrnn_ctx* c, int32_t C, bsrnn_stream** out)
     st->Y = p; p += (size_t)C * c->LDP;
     st->chunk = p; p += (size_t)C * HOPS;
     st->out = p; p += (size_t)C * HOPS;
-    st->use_graph = getenv("BSRNN_NO_GRAPH") == nullptr;
+    // The model part of a step as plain launches (default) or as one hipGraph per carry parity (BSRNN_STREAM_GRAPH=1).  Measured from C
+    // (tools/stream_cloop.cpp, profiles/r04_stream_kernels.txt): the graph launch of the 14 dependent kernel nodes costs the host MORE than
+    // 14 plain launches (78 vs 68 us inside the call) and the chunk 143.2 vs 139.5 us - the gaps between dependent kernels are the same
+    // inside a replayed graph - so the cheaper form is the default; the graph path stays for A/B (BSRNN_NO_GRAPH is accepted and means the default).
+    st->use_graph = getenv("BSRNN_STREAM_GRAPH") != nullptr && getenv("BSRNN_NO_GRAPH") == nullptr;
     if (hipHostMalloc((void**)&st->h_in, (size_t)C * HOPS * sizeof(float), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&st->h_out, (size_t)C * HOPS * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         (void)hipFree(st->base); delete st; return fail(BSRNN_EHIP, "hipHostMalloc failed");

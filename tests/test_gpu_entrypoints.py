@@ -126,7 +126,9 @@ def test_ladspa_run_does_no_first_use_work(weight_file):
     h = d.instantiate(None, 44100)
     assert h
     ready = counters()
-    assert ready[1] - before[1] == 2 and ready[2] - before[2] == 2       # both parity graphs were made in instantiate()
+    graph = os.environ.get("BSRNN_STREAM_GRAPH") is not None
+    if graph:
+        assert ready[1] - before[1] == 2 and ready[2] - before[2] == 2   # both parity graphs were made in instantiate()
     launches0 = _native.lib.bsrnn_debug_counter(3)
     wave = weights.synth_waveform(2, 64 * 1024, seed=9)
     control = np.array([1.0], np.float32)
@@ -142,11 +144,21 @@ def test_ladspa_run_does_no_first_use_work(weight_file):
         if k == 1:
             assert counters() == ready, "run() allocated, captured or instantiated on its first chunks"
     assert counters() == ready
-    assert _native.lib.bsrnn_debug_counter(3) - launches0 == 64            # every chunk was a graph replay
+    assert _native.lib.bsrnn_debug_counter(3) - launches0 == (64 if graph else 0)      # (BSRNN_STREAM_GRAPH=1: every chunk a graph replay)
     d.cleanup(h)
     steady = float(np.median(times[8:]))
     print("ladspa run(): first chunks %.0f / %.0f us, steady state %.0f us" % (1e6 * times[0], 1e6 * times[1], 1e6 * steady))
     assert times[0] <= 2.0 * steady + 50e-6 and times[1] <= 2.0 * steady + 50e-6, (times[:4], steady)
+
+
+def test_ladspa_run_with_the_step_as_a_graph(weight_file):
+    """BSRNN_STREAM_GRAPH=1 (A/B: the model part of a step as one hipGraph per carry parity, captured and instantiated in instantiate()):
+    the same no-first-use-work guarantees, in a child process (the plugin reads the switch when it creates its stream)."""
+    env = dict(os.environ, BSRNN_STREAM_GRAPH="1", BSRNN_WEIGHTS=weight_file, PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-s", "-k", "test_ladspa_run_does_no_first_use_work",
+                        "-p", "no:cacheprovider"], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    print(r.stdout[-1200:])
+    assert r.returncode == 0, r.stdout[-3000:]
 
 
 def test_ladspa_in_place_buffers(weight_file):

@@ -15,12 +15,13 @@ f = glob.glob("gpurun_out/prof_%s/*/*kernel_trace.csv" % tag)
 assert f, "no kernel_trace.csv"
 rows = list(csv.DictReader(open(f[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# the timed loop's steps: every stft_kernel starts one; take the 8th of the 12 timed ones from the end
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("bsrnn::stft_kernel") or "stft_kernel" in r["Kernel_Name"]]
+# every stft_kernel starts a step: bench.py runs 64 pre-warm + 2 warm-up steps, then the 12 timed ones (later steps belong to its serial
+# second context and the other sub-measurements)
+starts = [i for i, r in enumerate(rows) if "stft_kernel" in r["Kernel_Name"]]
 out = open("gpurun_out/%s_timeline.txt" % tag, "w")
 def emit(s):
     print(s); out.write(s + "\n")
-for which in (-12, -11):
+for which in (70, 71):
     i0 = starts[which]; i1 = starts[which + 1]
     t0 = int(rows[i0]["Start_Timestamp"])
     emit("step starting at kernel #%d (%d kernels): start us / end us / duration us / queue / kernel" % (i0, i1 - i0))

@@ -68,15 +68,15 @@ def main():
             "%.0f" % (100 * busy / 1024 / (gui / 8)) if gui else "-"))
     if len(extra) == 3:
         l_, d_, v_ = per_dispatch(extra[0]), per_dispatch(extra[1]), per_dispatch(extra[2])
-        lines += ["", "What bounds the kernels (separate PMC passes; per launch).  L1 -> L2 read MB = TCP_TCC_READ_REQ x 64 B (requests of 64 B;"
-                  " a 128 B line read = 2), GB/s per CU = that / avg us / 256 CUs; L1 stalled on L2 = TCP_PENDING_STALL_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs);"
+        lines += ["", "What bounds the kernels (separate PMC passes; per launch).  L1 -> L2 read MB = TCP_TCC_READ_REQ x 128 B (one request per 128-B line:"
+                  " calibrated on the fused chains, whose fragment streams are known byte for byte - 2.15 / 2.38 GB per launch), GB/s per CU = that / avg us / 256 CUs; L1 stalled on L2 = TCP_PENDING_STALL_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs);"
                   " LDS: bank-conflict cycles / LDS-active cycles, and the share of wave cycles spent waiting on LDS instructions; waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES.", "",
                   "| kernel | L1->L2 read MB | L1->L2 write MB | L2->CU GB/s per CU | L1 stalled on L2 % | LDS conflict % of LDS cycles | wave cycles waiting on LDS % | wave cycles waiting (any) % |",
                   "|---|---|---|---|---|---|---|---|"]
         for k in sorted(dur, key=lambda x: -dur[x]):
             if "rocclr" in k or k not in l_:
                 continue
-            rd = l_[k].get("TCP_TCC_READ_REQ_sum", 0) * 64 / 1e6
+            rd = l_[k].get("TCP_TCC_READ_REQ_sum", 0) * 128 / 1e6
             wrq = l_[k].get("TCP_TCC_WRITE_REQ_sum", 0) * 64 / 1e6
             gui = s_.get(k, {}).get("GRBM_GUI_ACTIVE", 0)
             stall = l_[k].get("TCP_PENDING_STALL_CYCLES_sum", 0)
