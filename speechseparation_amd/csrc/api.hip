@@ -148,6 +148,17 @@ struct bsrnn_ctx {
     struct OvlTable { int2* mask_tasks; int n_mask; int* band_order; int n_ord; };
     std::map<std::pair<int, int>, OvlTable> ovl_tables;       // per (rows C, frames T): consumer dispatch orders by readiness
     hipEvent_t ev_ovl_fork = nullptr, ev_ovl_join = nullptr;
+    int ovl_epoch = 0;              // overlapped calls so far on this context (upper bits of the progress words, kernels.h); reset every 2^18
+    int ovl_resident_total[2] = {0, 0};      // time-axis workgroups the two resident counters have been promised so far (the gates' targets)
+    bool ovl_unjoined = false;      // the auxiliary stream may still be draining the last overlapped call (a host-side join follows where one is needed)
+    // How a consumer launch is held back until every workgroup of its producer is resident: a one-wave gate kernel that spins on the
+    // resident counter (default).  A resident foreign wave costs a band launch its pairing (its partners sit 8 ids apart and complete inside
+    // one round of 512 slots; with 511 the last eight pairs straddle two rounds: +18 us), so the gates are kept off the band launches'
+    // dispatch by events (fork in front of gate 0, a mid event between band 1 and gate 1).  BSRNN_OVL_GATE=cp (measured and rejected,
+    // profiles/r04_gate_kernel_vs_cp.txt): hipStreamWaitValue32 on 8-byte signal words - on this runtime not a command-processor wait but
+    // a blit kernel (__amd_rocclr_streamOpsWait) that spins so hard that the time-axis launch beside it takes 3x as long (1.37 ms per step).
+    int* ovl_sig[2] = {nullptr, nullptr};
+    hipEvent_t ev_ovl_mid = nullptr;
 
     // concurrent row blocks of one call (bsrnn_separate)
     // BSRNN_PARTS / BSRNN_PART_LAG.  0 = automatic: two row blocks on two streams from 128 rows on (blocks of >= 64 rows), the
@@ -456,7 +467,7 @@ struct Part {
     const float* wave; float* wave_out; int64_t n;       // only for the fused sandwich
     const bsrnn_ctx::OvlTable* ovl;                      // non-null: the overlapped flow (run_overlapped) - producers publish, consumers wait
     int ovl_mode;                                        // ... which of the two hand-overs (bsrnn_ctx::overlap_mode)
-    int ovl_zero_blk;                                    // the band block (0 / 1) whose launch clears the progress words, -1: none
+    int ovl_base;                                        // this call's epoch << OVL_EPOCH_SHIFT
 };
 
 Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s, int j = 0)
@@ -524,13 +535,12 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         const bool parts = ctx_parts(c);
         const float* zi = parts && blk ? p.Z1 : p.Z0;
         if (ctx_pair(c)) {                        // both layers in one launch (A/B: BSRNN_BAND_PAIR=0)
-            OvlConsumer oc = {nullptr, 0, 0, nullptr};
+            OvlConsumer oc = {nullptr, 0, 0, nullptr, 0};
             const bool cons = p.ovl && blk && (p.ovl_mode & 1);
             if (cons)                             // beside the first time-axis launch: tiles in the order their frames leave it
-                oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT, p.ovl->band_order};
+                oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT, p.ovl->band_order, p.ovl_base};
             launch_band_pair(zi, p.HB0, p.HB1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1], M, K, c->d_range, s,
-                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr,
-                             p.ovl && p.ovl_zero_blk == blk ? c->d_ovl : nullptr, 2 * c->ovl_stride);
+                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr);
             break;
         }
         launch_band_lstm(zi, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
@@ -550,9 +560,9 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         // fp16x2 mode: the launch also computes the block's fc + residual (out = fc(h1) + Z1 -> Z0); otherwise it writes h1
         const bool fused = time_lstm_fuses_fc();
         if (ctx_parts(c) && !band_block_is_small(M, K)) {
-            OvlProducer op = {nullptr, nullptr};
+            OvlProducer op = {nullptr, nullptr, 0};
             const bool prod = p.ovl && (p.ovl_mode & (blk ? 2 : 1));
-            if (prod) op = OvlProducer{c->d_ovl + blk * c->ovl_stride, c->overlap_sabotage ? nullptr : c->d_ovl + blk * c->ovl_stride + OVL_HEAD};
+            if (prod) op = OvlProducer{c->ovl_sig[blk] ? c->ovl_sig[blk] : c->d_ovl + blk * c->ovl_stride, c->overlap_sabotage ? nullptr : c->d_ovl + blk * c->ovl_stride + OVL_HEAD, p.ovl_base};
             launch_time_lstm(blk ? p.Z1 : p.Z0, blk ? p.Z0 : p.Z1, c->timeW[blk], c->timeW16[blk], c->timeB[blk],
                              p.state_in ? p.state_in + blk * p.state_slab : nullptr,
                              p.state_out ? p.state_out + blk * p.state_slab : nullptr, p.C, p.T, K, c->d_range, s,
@@ -587,6 +597,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
                 g.tasks = p.ovl->mask_tasks; g.n_tasks = p.ovl->n_mask;
                 g.ovl_prog = c->d_ovl + c->ovl_stride + OVL_HEAD; g.ovl_T = p.T; g.ovl_K = K;
                 g.ovl_spin = c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT;
+                g.ovl_base = p.ovl_base;
             }
             launch_mlp_chain(g, CHAIN_MASK, s);
             break;
@@ -614,7 +625,7 @@ static bool overlap_wanted(const bsrnn_ctx* c, int C, int T)
 {
     if (!c->overlap_env || c->overlap_off || !ctx_parts(c) || !c->fused || force_f32() || gemm_mode() == GEMM_F32) return false;
     const int nwg = (C * c->K + 3) / 4;
-    return !band_block_is_small(C * T, c->K) && nwg >= 32 && nwg <= 224 && T >= 32 && C * T > GEMV_MAX_FRAME_ROWS;
+    return !band_block_is_small(C * T, c->K) && nwg >= 32 && nwg <= 224 && T >= 32 && T < (4 << OVL_EPOCH_SHIFT) - 8 && C * T > GEMV_MAX_FRAME_ROWS;
 }
 static void free_ovl_tables(bsrnn_ctx* c)
 {
@@ -629,6 +640,21 @@ int ensure_ovl(bsrnn_ctx* c, int C, int T)
     if (rc) return rc;
     if (!c->ev_ovl_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_fork, hipEventDisableTiming));
     if (!c->ev_ovl_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_join, hipEventDisableTiming));
+    if (!c->ev_ovl_mid) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_mid, hipEventDisableTiming));
+    static const bool want_cp = [] { const char* e = getenv("BSRNN_OVL_GATE"); return e && !strcmp(e, "cp"); }();
+    if (want_cp && !c->ovl_sig[0]) {
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+        for (int b = 0; b < 2 && can; ++b) {
+            ++g_dbg[DBG_ALLOC];
+            if (hipExtMallocWithFlags((void**)&c->ovl_sig[b], 8, hipMallocSignalMemory) != hipSuccess || hipMemset(c->ovl_sig[b], 0, 8) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int k = 0; k <= b; ++k) if (c->ovl_sig[k]) { (void)hipFree(c->ovl_sig[k]); c->ovl_sig[k] = nullptr; }
+                can = 0;                          // (the kernel gates take over)
+            }
+        }
+        if (c->ovl_sig[0]) c->ovl_resident_total[0] = c->ovl_resident_total[1] = 0;
+    }
     const int M = C * T, K = c->K, nwg = (C * K + 3) / 4;
     const int stride = OVL_HEAD + ((nwg + 15) & ~15);
     if (stride > c->ovl_stride) {
@@ -637,6 +663,7 @@ int ensure_ovl(bsrnn_ctx* c, int C, int T)
         HIP_TRY(hipMalloc((void**)&c->d_ovl, (size_t)2 * stride * sizeof(int)));
         HIP_TRY(hipMemset(c->d_ovl, 0, (size_t)2 * stride * sizeof(int)));
         c->ovl_stride = stride;
+        if (!c->ovl_sig[0]) c->ovl_resident_total[0] = c->ovl_resident_total[1] = 0;       // (fresh counters; the epochs go on: fresh words are below every base)
         ++c->gen;
     }
     const auto key = std::make_pair(C, T);
@@ -700,37 +727,71 @@ void run_overlapped(bsrnn_ctx* c, Part p, const bsrnn_ctx::OvlTable* tb, int fir
     p.ovl = tb;
     p.ovl_mode = c->overlap_mode;
     const bool band = p.ovl_mode & 1, mask = p.ovl_mode & 2, serial = p.ovl_mode & 4;
-    p.ovl_zero_blk = band ? 0 : 1;                // the last band launch in front of the fork clears the progress words
     Part pb = p;
     if (!serial) pb.s = B;
     const int nwg = (p.C * c->K + 3) / 4, limit = OVL_SPIN_LIMIT;
+    // this call's epoch (upper bits of every progress word it publishes or waits for) and the gates' targets (running totals)
+    if (++c->ovl_epoch >= (1 << 18) || c->ovl_resident_total[0] > (1 << 30) || c->ovl_resident_total[1] > (1 << 30)) {   // start again: nothing in flight, every word zero
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(c->d_ovl, 0, (size_t)2 * c->ovl_stride * sizeof(int));
+        for (int b = 0; b < 2; ++b) if (c->ovl_sig[b]) (void)hipMemset(c->ovl_sig[b], 0, 8);
+        c->ovl_epoch = 1; c->ovl_resident_total[0] = c->ovl_resident_total[1] = 0;
+    }
+    p.ovl_base = pb.ovl_base = c->ovl_epoch << OVL_EPOCH_SHIFT;
+    if (band) c->ovl_resident_total[0] += nwg;
+    if (mask) c->ovl_resident_total[1] += nwg;
+    const bool cp = c->ovl_sig[0] != nullptr && !serial;
+    // hold stream `s` until every workgroup of time launch `blk` of THIS call is resident
+    auto gate = [&](int blk, hipStream_t s) {
+        if (cp) (void)hipStreamWaitValue32(s, c->ovl_sig[blk], (uint32_t)c->ovl_resident_total[blk], hipStreamWaitValueGte, 0xffffffffu);
+        else launch_ovl_gate(c->d_ovl + blk * c->ovl_stride, c->ovl_resident_total[blk], c->d_range, limit, s);
+    };
     for (int st = first; st <= MS_BANDSPLIT; ++st) run_stage(c, p, st);
     run_stage(c, p, MS_BAND0);
-    auto fork = [&]() { if (!serial) { (void)hipEventRecord(c->ev_ovl_fork, A); (void)hipStreamWaitEvent(B, c->ev_ovl_fork, 0); } };
-    auto join = [&]() { if (!serial) { (void)hipEventRecord(c->ev_ovl_join, B); (void)hipStreamWaitEvent(A, c->ev_ovl_join, 0); } };
+    // The auxiliary stream is joined on the host where something needs it (finish_call under the default range policy, bsrnn_sync, a stream
+    // switch) or by an event for a call that returns LSTM state; a join event in front of the iSTFT cost the caller's stream a 6 us gap.
+    auto join = [&]() {
+        if (serial) return;
+        if (p.state_out) { (void)hipEventRecord(c->ev_ovl_join, B); (void)hipStreamWaitEvent(A, c->ev_ovl_join, 0); }
+        else c->ovl_unjoined = true;
+    };
     if (band) {
-        fork();
+        // command-processor gates: the auxiliary stream is ordered behind the caller's by the words alone (no fork).  Kernel gates: the
+        // fork event keeps gate 0 off band 0's dispatch, and gate 1 waits (event) until band 1 has been dispatched completely.
+        if (!cp && !serial) { (void)hipEventRecord(c->ev_ovl_fork, A); (void)hipStreamWaitEvent(B, c->ev_ovl_fork, 0); }
         run_stage(c, p, MS_TIME0);
-        launch_ovl_gate(c->d_ovl, nwg, c->d_range, limit, pb.s);
+        gate(0, pb.s);
         run_stage(c, pb, MS_BAND1);
+        if (!cp && !serial && mask) (void)hipEventRecord(c->ev_ovl_mid, B);
         run_stage(c, pb, MS_TIME1);
-        if (mask) launch_ovl_gate(c->d_ovl + c->ovl_stride, nwg, c->d_range, limit, A);
-        else join();
+        if (mask) {
+            if (!cp && !serial) (void)hipStreamWaitEvent(A, c->ev_ovl_mid, 0);
+            gate(1, A);
+        } else if (!serial) { (void)hipEventRecord(c->ev_ovl_join, B); (void)hipStreamWaitEvent(A, c->ev_ovl_join, 0); }      // (the mask chain does not wait per workgroup)
         run_stage(c, p, MS_MASK);
         if (mask) join();
     } else {                                      // the mask chain alone beside the second time-axis launch
         run_stage(c, p, MS_TIME0);
         run_stage(c, p, MS_BAND1);
-        fork();
+        if (!serial) { (void)hipEventRecord(c->ev_ovl_fork, A); (void)hipStreamWaitEvent(B, c->ev_ovl_fork, 0); }           // (time 1 reads what band 1 wrote)
         run_stage(c, pb, MS_TIME1);
-        launch_ovl_gate(c->d_ovl + c->ovl_stride, nwg, c->d_range, limit, A);
+        gate(1, A);
         run_stage(c, p, MS_MASK);
         join();
     }
     for (int st = MS_MASK + 1; st <= last; ++st) run_stage(c, p, st);
+    // A command-processor wait has no time-out of its own: if a launch of this call failed, its producer may never arrive - release the waits
+    // from the host (the caller gets the launch error through hipGetLastError at the end of the entry point).
+    if (cp && hipPeekAtLastError() != hipSuccess)
+        for (int b = 0; b < 2; ++b) *(volatile int*)c->ovl_sig[b] = c->ovl_resident_total[b];      // (signal memory is host-visible)
 }
-// (a call that is being captured into a caller's hipGraph runs launch after launch: a graph is replayed by whoever owns it, possibly beside
-//  other replays of itself on other streams, and the progress words belong to ONE call in flight per context)
+// host-side join of the auxiliary stream with the last overlapped call (see run_overlapped)
+static int ovl_join_host(bsrnn_ctx* c)
+{
+    if (c->ovl_unjoined && c->aux[0]) HIP_TRY(hipStreamSynchronize(c->aux[0]));
+    c->ovl_unjoined = false;
+    return 0;
+}
 static const bsrnn_ctx::OvlTable* ovl_table(const bsrnn_ctx* c, int C, int T, hipStream_t s)
 {
     if (!overlap_wanted(c, C, T) || !c->d_ovl) return nullptr;
@@ -793,6 +854,7 @@ int finish_call(bsrnn_ctx* c, hipStream_t s, F&& rerun)
     if (c->range_policy != BSRNN_RANGE_EXACT || !c->h_range || force_f32()) return 0;
     if (gemm_mode() == GEMM_F32 && lstm_mode() == LSTM_F32) return 0;
     HIP_TRY(hipStreamSynchronize(s));
+    if (int rcj = ovl_join_host(c)) return rcj;      // (the second time-axis launch of an overlapped call ran on the auxiliary stream: its guard word too)
     const int v = *(volatile int*)c->h_range;
     if (!v) return 0;
     *(volatile int*)c->h_range = 0;
@@ -806,6 +868,7 @@ int finish_call(bsrnn_ctx* c, hipStream_t s, F&& rerun)
         ++c->gen;                                 // (a streaming graph captured with the old flow is re-captured by the re-run)
         if (int rc4 = rerun()) return rc4;
         HIP_TRY(hipStreamSynchronize(s));
+        if (int rcj = ovl_join_host(c)) return rcj;
         vv = *(volatile int*)c->h_range;
         if (!vv) return 0;
         *(volatile int*)c->h_range = 0;
@@ -847,7 +910,7 @@ struct CallGuard {
 // call's kernels may touch it.  Same stream (the normal case): stream order does it, nothing to do here.
 int order_after_last(bsrnn_ctx* c, hipStream_t s)
 {
-    if (c->have_last && c->last_stream != s) HIP_TRY(hipStreamSynchronize(c->last_stream));
+    if (c->have_last && c->last_stream != s) { HIP_TRY(hipStreamSynchronize(c->last_stream)); if (int rcj = ovl_join_host(c)) return rcj; }
     c->last_stream = s; c->have_last = true;
     return 0;
 }
@@ -974,6 +1037,8 @@ static void destroy_now(bsrnn_ctx* c)
     if (c->ev_ovl_join) (void)hipEventDestroy(c->ev_ovl_join);
     free_ovl_tables(c);
     if (c->d_ovl) (void)hipFree(c->d_ovl);
+    for (int b = 0; b < 2; ++b) if (c->ovl_sig[b]) (void)hipFree(c->ovl_sig[b]);
+    if (c->ev_ovl_mid) (void)hipEventDestroy(c->ev_ovl_mid);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_tap) (void)hipFree(c->d_tap);
     if (c->d_arena) (void)hipFree(c->d_arena);
@@ -2341,6 +2406,7 @@ int bsrnn_sync(bsrnn_ctx* c, void* stream)
     if (!c) return fail(BSRNN_EARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (int rcj = ovl_join_host(c)) return rcj;
     return check_range(c);
 }
 

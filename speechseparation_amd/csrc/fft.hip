@@ -187,8 +187,14 @@ static int frames_per_workgroup(int units, int rows, int slots, int extra)
 // One workgroup transforms `sch` consecutive frames of one row.  Frames overlap by half: the thread that owns complex
 // samples c + 512, c + 768 of frame t owns c, c + 256 of frame t + 1, so only the new half is loaded per frame
 // (requested before the FFT passes of the current frame) and the raw samples stay in registers.
+#ifndef FFT_OCC_STFT
+#define FFT_OCC_STFT 4            // waves per SIMD (= workgroups per CU) the offline STFT is compiled for (A/B: tools/fft_variants.sh)
+#endif
+#ifndef FFT_OCC_ISTFT
+#define FFT_OCC_ISTFT 4
+#endif
 template <bool ZERO_PAD>      // ZERO_PAD: samples outside [0, n) are zeros instead of reflections (the adjoint of the iSTFT, below)
-__global__ __launch_bounds__(256) void stft_kernel(FftTables tb, const float* __restrict__ wave, float* __restrict__ X,
+__global__ __launch_bounds__(256, FFT_OCC_STFT) void stft_kernel(FftTables tb, const float* __restrict__ wave, float* __restrict__ X,
                                                    int64_t n, int T, int sch)
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
@@ -292,7 +298,7 @@ void launch_istft_backward(const FftTables& tb, const float* dwave, float* scrat
 // samples c, c + 256 of a frame's first half also owns c + 512, c + 768 of the second half) and recomputes one
 // frame per chunk - no [M][2048] frame buffer in HBM and no separate overlap-add launch (was 132 MB + 15 us).
 // The spectrum of frame t + 1 is requested before the FFT passes of frame t.
-__global__ __launch_bounds__(256) void istft_fused_kernel(FftTables tb, const float* __restrict__ Y, float* __restrict__ out, int T, int ich)
+__global__ __launch_bounds__(256, FFT_OCC_ISTFT) void istft_fused_kernel(FftTables tb, const float* __restrict__ Y, float* __restrict__ out, int T, int ich)
 {
     __shared__ __attribute__((aligned(16))) float2 z0[1024], z1[1024];
 #ifdef FFT_EXCLUSIVE_LDS

@@ -112,7 +112,7 @@ struct ChainLaunch {
     unsigned long long* dbg;         // measurement only (CHAIN_TRACE builds of tools/chain_bench.hip): per-wave phase stamps
     // MASK chain launched BESIDE the time-axis launch that produces its input (api.hip, overlapped dual path): every workgroup first
     // waits until the frames of its rows have left that launch (OvlConsumer below); null = the input is complete at launch
-    const int* ovl_prog; int ovl_T, ovl_K, ovl_spin;
+    const int* ovl_prog; int ovl_T, ovl_K, ovl_spin, ovl_base;
 };
 // rows per workgroup of a descriptor (32 RT GR; 256 for a constant band)
 __host__ __device__ inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : (d.RT >= 3 ? 16 * d.RT : 32 * d.RT * (8 / d.NW)); }   // RT >= 3: row tiles of 16 (16 x 16 x 32 geometry: 48 or 80 rows)
@@ -129,8 +129,13 @@ void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 //       acquire, workgroup barrier, then plain loads (cdna_hip_programming.md, Guideline 16).  A wait that expires is REPORTED (range
 //       flag value 5: api.hip runs the call again launch after launch and stops overlapping), never computed with.
 // All words are zeroed in stream order before the producers of a call start; nothing travels by value that changes from call to call.
-struct OvlProducer { int* resident; int* prog; };
-struct OvlConsumer { const int* prog; int T; int spin_limit; const int* order; };   // spin_limit: 100 MHz ticks a wait may last   // order (band launch): dispatch ordinal -> tile of 16 sequences, by the time its frames are ready
+// Progress words carry the CALL'S EPOCH in their upper bits (api.hip counts overlapped calls per context): prog[wg] = epoch << 12 | groups done,
+// raised with an atomic max; the resident counters only ever grow and a gate waits for the context's running total.  So nothing is zeroed per
+// call and nothing orders the consumer's stream behind the producer's except the words themselves (an overlapped call is never captured into
+// a graph - api.hip - so by-value epochs cannot go stale; every 2^18 calls the host drains the device and starts the epochs again).
+struct OvlProducer { int* resident; int* prog; int base; };                          // base = epoch << OVL_EPOCH_SHIFT
+struct OvlConsumer { const int* prog; int T; int spin_limit; const int* order; int base; };   // spin_limit: 100 MHz ticks a wait may last
+constexpr int OVL_EPOCH_SHIFT = 12;            // groups of four steps per launch < 4096 (frames < 16 384: api.hip checks)   // order (band launch): dispatch ordinal -> tile of 16 sequences, by the time its frames are ready
 constexpr int OVL_SPIN_LIMIT = 20000000;       // 100 MHz ticks (s_memrealtime) before a wait gives up: 200 ms - a healthy wait lasts as long as a
                                                // time-axis launch (0.1 ... a few ms); under a tool that serialises kernels (rocprofv3 --pmc) the
                                                // producer never runs beside the consumer: the call falls back after this long, once per context
@@ -138,7 +143,7 @@ void launch_ovl_gate(const int* resident, int target, int* range_flag, int spin_
 #if defined(__HIPCC__)
 // frame rows m_first .. m_last (m = batch row * T + frame) of bands k_first .. k_last: wait until every time-axis workgroup that owns one
 // of those sequences (n = batch row * K + band, four per workgroup) has published the groups that cover the frames.  ONE lane calls this.
-__device__ __forceinline__ bool ovl_wait_rows(const int* prog, int m_first, int m_last, int T, int K, int k_first, int k_last, int limit)
+__device__ __forceinline__ bool ovl_wait_rows(const int* prog, int m_first, int m_last, int T, int K, int k_first, int k_last, int limit, int base)
 {
     typedef const int __attribute__((address_space(1)))* gci;
     const gci pg = (gci)prog;
@@ -146,7 +151,7 @@ __device__ __forceinline__ bool ovl_wait_rows(const int* prog, int m_first, int 
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (int r = r_a; r <= r_b; ++r) {
         const int t_last = r < r_b ? T - 1 : m_last - r * T;
-        const int need = (t_last >> 2) + 1;
+        const int need = base + (t_last >> 2) + 1;
         for (int wg = (r * K + k_first) >> 2; wg <= (r * K + k_last) >> 2; ++wg)
             while (__hip_atomic_load(pg + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(16);

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void band_pair_h2_kernel(const float* __res
         // launched beside the time-axis launch that writes z (kernels.h, OvlConsumer): wait until this tile's 16 frame rows have left it
         if (threadIdx.x == 0) {
             const int m_last = tile * 16 + 15 < N ? tile * 16 + 15 : N - 1;
-            partner_ok = ovl_wait_rows(ovl.prog, tile * 16, m_last, ovl.T, L, 0, L - 1, ovl.spin_limit) ? 1 : 0;
+            partner_ok = ovl_wait_rows(ovl.prog, tile * 16, m_last, ovl.T, L, 0, L - 1, ovl.spin_limit, ovl.base) ? 1 : 0;
         }
         __syncthreads();
         if (!partner_ok) {                        // (value 5: api.hip runs the call again launch after launch and stops overlapping)
@@ -611,7 +611,7 @@ void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16
                       int* zero_words, int zero_n)
 {
     if (N <= 0 || L <= 0) return;
-    OvlConsumer ovl = {nullptr, 0, 0, nullptr};
+    OvlConsumer ovl = {nullptr, 0, 0, nullptr, 0};
     if (ovlp) ovl = *ovlp;
     const dim3 grid((((N + 15) / 16 + 7) / 8) * 16), block(256);
     // test hook (tests/test_gpu_edges.py): BSRNN_BAND_PAIR=mismatch makes every workgroup publish a wrong XCC id, as if its partner sat on
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                                                              const uint4* __restrict__ wfc, const float* __restrict__ bfc,
                                                              const float* __restrict__ state_in, float* __restrict__ state_out,
                                                              int R, int T, int K, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
-                                                             const float* __restrict__ part = nullptr, int* ovl_resident = nullptr, int* ovl_prog = nullptr)
+                                                             const float* __restrict__ part = nullptr, int* ovl_resident = nullptr, int* ovl_prog = nullptr, int ovl_base = 0)
 {
     unsigned long long tp[4] = {0, 0, 0, 0}, tq = 0;          // measurement only
     auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
     if (tid < SY_COUNT) sync[tid] = 0;
     if (tid >= 64 && tid < 72) outc[tid - 64] = 0;
     // overlapped dual path (kernels.h, OvlProducer): this workgroup is on the chip - the launch that consumes its output is let go when all are
-    if (PART && tid == 0 && ovl_resident) __hip_atomic_fetch_add(ovl_resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PART && tid == 0 && ovl_resident) __hip_atomic_fetch_add(ovl_resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (may be a signal word the command processor polls)
     if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
 
     // The two role families are laid out as "helpers: ...; return;  main waves: ..." and not as if / else: with a join behind both, the
@@ -1379,7 +1379,8 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
                 int old = 0;
                 if (lane == 0) old = __hip_atomic_fetch_add(&outc[(f >> 2) & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 old = __builtin_amdgcn_readfirstlane(old);
-                if ((old & 3) == 3 && lane == 0) __hip_atomic_fetch_add(ovl_prog + blockIdx.x, (f & 3) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (absolute value, epoch in the upper bits, atomic MAX: the four-group publishes of a workgroup may come from different waves out of order)
+                if ((old & 3) == 3 && lane == 0) __hip_atomic_fetch_max(ovl_prog + blockIdx.x, ovl_base + f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
             auto fc_finish = [&](int f) {
                 if (pub && f >= 1) publish(f - 1);
@@ -1772,7 +1773,7 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const voi
         if (time_lstm_fuses_fc() && fc16 && fcb && part)
             hipLaunchKernelGGL((time_lstm_h2w_kernel<true, false, true>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
                                state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr, part, ovl ? ovl->resident : (int*)nullptr,
-                               ovl ? ovl->prog : (int*)nullptr);
+                               ovl ? ovl->prog : (int*)nullptr, ovl ? ovl->base : 0);
         else if (time_lstm_fuses_fc() && fc16 && fcb)
             hipLaunchKernelGGL((time_lstm_h2w_kernel<true, false>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
                                state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr);
@@ -1795,7 +1796,7 @@ __global__ void ovl_gate_kernel(const int* resident, int target, int* range_flag
     if (threadIdx.x) return;
     typedef const int __attribute__((address_space(1)))* gci;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load((gci)resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load((gci)resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {        // (a running total)
         __builtin_amdgcn_s_sleep(32);
         if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) { if (range_flag) *range_flag = 5; return; }
     }
