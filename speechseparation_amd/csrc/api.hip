@@ -638,9 +638,9 @@ int ensure_ovl(bsrnn_ctx* c, int C, int T)
     if (!overlap_wanted(c, C, T)) return 0;
     int rc = ensure_streams(c, 1);
     if (rc) return rc;
-    if (!c->ev_ovl_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_fork, hipEventDisableTiming));
-    if (!c->ev_ovl_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_join, hipEventDisableTiming));
-    if (!c->ev_ovl_mid) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_mid, hipEventDisableTiming));
+    if (!c->ev_ovl_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_fork, hipEventDisableTiming | hipEventDisableSystemFence));      // (device-side ordering only: no system-scope release on the record)
+    if (!c->ev_ovl_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_join, hipEventDisableTiming | hipEventDisableSystemFence));
+    if (!c->ev_ovl_mid) HIP_TRY(hipEventCreateWithFlags(&c->ev_ovl_mid, hipEventDisableTiming | hipEventDisableSystemFence));
     static const bool want_cp = [] { const char* e = getenv("BSRNN_OVL_GATE"); return e && !strcmp(e, "cp"); }();
     if (want_cp && !c->ovl_sig[0]) {
         int can = 0;
