@@ -468,6 +468,7 @@ struct Part {
     const bsrnn_ctx::OvlTable* ovl;                      // non-null: the overlapped flow (run_overlapped) - producers publish, consumers wait
     int ovl_mode;                                        // ... which of the two hand-overs (bsrnn_ctx::overlap_mode)
     int ovl_base;                                        // this call's epoch << OVL_EPOCH_SHIFT
+    hipEvent_t band_done[2];                             // events the two band launches signal themselves when they complete (or null)
 };
 
 Part make_part(bsrnn_ctx* c, int row0, int C, int T, hipStream_t s, int j = 0)
@@ -540,7 +541,8 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
             if (cons)                             // beside the first time-axis launch: tiles in the order their frames leave it
                 oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT, p.ovl->band_order, p.ovl_base};
             launch_band_pair(zi, p.HB0, p.HB1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1], M, K, c->d_range, s,
-                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr);
+                             parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr, nullptr, 0,
+                             p.ovl ? p.band_done[blk] : nullptr);
             break;
         }
         launch_band_lstm(zi, p.HB0, c->bandW[blk][0], c->bandW16[blk][0], c->bandB[blk][0], M, K, 64, c->d_range, s);
@@ -746,6 +748,9 @@ void run_overlapped(bsrnn_ctx* c, Part p, const bsrnn_ctx::OvlTable* tb, int fir
         if (cp) (void)hipStreamWaitValue32(s, c->ovl_sig[blk], (uint32_t)c->ovl_resident_total[blk], hipStreamWaitValueGte, 0xffffffffu);
         else launch_ovl_gate(c->d_ovl + blk * c->ovl_stride, c->ovl_resident_total[blk], c->d_range, limit, s);
     };
+    const bool ev_in_launch = band && !cp && !serial;
+    p.band_done[0] = pb.band_done[0] = ev_in_launch ? c->ev_ovl_fork : nullptr;
+    p.band_done[1] = pb.band_done[1] = ev_in_launch && mask ? c->ev_ovl_mid : nullptr;
     for (int st = first; st <= MS_BANDSPLIT; ++st) run_stage(c, p, st);
     run_stage(c, p, MS_BAND0);
     // The auxiliary stream is joined on the host where something needs it (finish_call under the default range policy, bsrnn_sync, a stream
@@ -758,11 +763,10 @@ void run_overlapped(bsrnn_ctx* c, Part p, const bsrnn_ctx::OvlTable* tb, int fir
     if (band) {
         // command-processor gates: the auxiliary stream is ordered behind the caller's by the words alone (no fork).  Kernel gates: the
         // fork event keeps gate 0 off band 0's dispatch, and gate 1 waits (event) until band 1 has been dispatched completely.
-        if (!cp && !serial) { (void)hipEventRecord(c->ev_ovl_fork, A); (void)hipStreamWaitEvent(B, c->ev_ovl_fork, 0); }
+        if (!cp && !serial) (void)hipStreamWaitEvent(B, c->ev_ovl_fork, 0);          // (signalled by band 0's own dispatch: p.band_done)
         run_stage(c, p, MS_TIME0);
         gate(0, pb.s);
-        run_stage(c, pb, MS_BAND1);
-        if (!cp && !serial && mask) (void)hipEventRecord(c->ev_ovl_mid, B);
+        run_stage(c, pb, MS_BAND1);                                                  // (... and the mid event by band 1's)
         run_stage(c, pb, MS_TIME1);
         if (mask) {
             if (!cp && !serial) (void)hipStreamWaitEvent(A, c->ev_ovl_mid, 0);

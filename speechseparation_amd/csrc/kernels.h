@@ -186,7 +186,7 @@ bool band_fc_in_parts();
 bool band_pair_enabled();
 void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
                       int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags,
-                      const OvlConsumer* ovl = nullptr, int* zero_words = nullptr, int zero_n = 0);   // zero_words: progress words to clear (overlapped dual path)
+                      const OvlConsumer* ovl = nullptr, int* zero_words = nullptr, int zero_n = 0, hipEvent_t done = nullptr);   // zero_words: progress words to clear (overlapped dual path)
 // The whole band-axis block (both layers, both directions, fc + residual) of a few sequences in one workgroup: the streaming
 // step's N = C frame rows.  w0pk16 / w1pk16 / bias0 / bias1 are launch_band_lstm's arguments of the two layers; fc16 the block's
 // fc (128 -> 64) as fp16x2 B fragments [4 tile][4 blk][2 piece][64 lane][8], fcb its bias.  zout = fc(h1) + b + zin.

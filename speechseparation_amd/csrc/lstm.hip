@@ -11,6 +11,7 @@
 // (api.hip: W' = W_ih W_in, b' = W_ih b_in + b_ih + b_hh, in double), the trailing fc + residual
 // runs as one grouped-GEMM launch (gemm.hip, EPI_RES).
 #include "kernels.h"
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -608,7 +609,7 @@ bool band_pair_enabled()
 // both layers of a band block as one launch (band_pair_h2_kernel); fc16 / fcb as launch_band_lstm's (shares of the fc) or null
 void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16, const float* bias0, const void* w1pk16, const float* bias1,
                       int N, int L, int* range_flag, hipStream_t stream, const void* fc16, const float* fcb, int* flags, const OvlConsumer* ovlp,
-                      int* zero_words, int zero_n)
+                      int* zero_words, int zero_n, hipEvent_t done)
 {
     if (N <= 0 || L <= 0) return;
     OvlConsumer ovl = {nullptr, 0, 0, nullptr, 0};
@@ -617,12 +618,14 @@ void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16
     // test hook (tests/test_gpu_edges.py): BSRNN_BAND_PAIR=mismatch makes every workgroup publish a wrong XCC id, as if its partner sat on
     // another XCD - the launch reports it (guard value 4) and the context falls back to one launch per layer
     static const int sabotage = [] { const char* e = getenv("BSRNN_BAND_PAIR"); return (e && !strcmp(e, "mismatch")) ? 1 : 0; }();
+    // done: an event the launch itself signals when it completes (the completion signal of its own dispatch packet: hipExtLaunchKernel) - a
+    // separate hipEventRecord behind the launch is a marker packet of its own and cost the stream a 5-7 us gap (overlapped dual path)
     if (fc16)
-        hipLaunchKernelGGL((band_pair_h2_kernel<true>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
-                           range_flag, (const uint4*)fc16, fcb, flags, sabotage, ovl, zero_words, zero_n);
+        hipExtLaunchKernelGGL((band_pair_h2_kernel<true>), grid, block, 0, stream, nullptr, done, 0, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
+                              range_flag, (const uint4*)fc16, fcb, flags, sabotage, ovl, zero_words, zero_n);
     else
-        hipLaunchKernelGGL((band_pair_h2_kernel<false>), grid, block, 0, stream, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
-                           range_flag, (const uint4*)nullptr, (const float*)nullptr, flags, sabotage, ovl, zero_words, zero_n);
+        hipExtLaunchKernelGGL((band_pair_h2_kernel<false>), grid, block, 0, stream, nullptr, done, 0, z, hb0, hb1, (const uint4*)w0pk16, bias0, (const uint4*)w1pk16, bias1, N, L,
+                              range_flag, (const uint4*)nullptr, (const float*)nullptr, flags, sabotage, ovl, zero_words, zero_n);
 }
 
 // BSRNN_BAND_FC = part (default: the second band layer writes the two directions' shares of the block's fc, the time-axis launch adds
