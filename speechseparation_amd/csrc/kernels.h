@@ -80,6 +80,9 @@ struct ChainLayer {
     int leaky;           // LeakyReLU(0.01) after the layer
     unsigned w_off;      // byte offset of the layer's fragment streams inside ChainDesc::wstream
     int rag;             // 1: the last of the NTL feature tiles (<= 4 real features) is split over the k-steps of all waves (split_host.h)
+#ifdef CHAIN_PAIR_GEOMETRY
+    unsigned w_off1;     // paired geometry (ChainDesc::pair): the fragment streams of the workgroup that holds the upper half of K (w_off: the lower)
+#endif
 };
 constexpr int CHAIN_RAG_LDS = 8 * 1024;       // LDS behind the activation images that the partial sums of such a tile need
 struct ChainDesc {
@@ -96,7 +99,20 @@ struct ChainDesc {
     int a8;              // band width in columns rounded up to 8: what is written to P / Y (pad columns exactly zero)
     int z_off;           // first column of the band inside a Z row
     int constant;        // zero-width band (TrainableConstantModule, bsrnn.py:12-24): Z[:, z_off .. +64) = bias[0 .. 64)
+#ifdef CHAIN_PAIR_GEOMETRY
+    // Paired geometry (mlp_chain.hip::chain_body_pair; measured and NOT adopted, DESIGN.md section 4c: built only into tools/chain_bench.hip):
+    // TWO workgroups share 80 frame rows of the band; each keeps one half of K of every layer's input in LDS, multiplies it with ALL the
+    // layer's output features and hands the partial sums of the partner's half of the outputs over through L2 - the band's weights are
+    // streamed once per 80 rows instead of once per 48.  Then L[l].K16 = k-steps of 32 of HALF the layer's K, L[l].NTL = feature tiles of
+    // 16 of the whole layer; every width is a multiple of 64.
+    int pair;            // 1: this geometry; the task's x carries the half in bit 24
+    int pair_base;       // first pair index of this band inside ChainLaunch::exch / pflags (pair = pair_base + row0 / 80)
+#endif
 };
+#ifdef CHAIN_PAIR_GEOMETRY
+constexpr int PAIR_ROWS = 80, PAIR_NH = 384;           // rows of a pair, features of half an output at most (a band of 768 columns)
+constexpr size_t PAIR_EXCH_FLOATS = (size_t)2 * 2 * PAIR_ROWS * PAIR_NH;     // per pair: [sender][layer parity][row][feature of the receiver's half]
+#endif
 struct ChainLaunch {
     const ChainDesc* desc;   // device array
     const int2* tasks;       // device array [n_tasks]: (descriptor index, first frame row) of every workgroup, in dispatch order
@@ -113,6 +129,10 @@ struct ChainLaunch {
     // MASK chain launched BESIDE the time-axis launch that produces its input (api.hip, overlapped dual path): every workgroup first
     // waits until the frames of its rows have left that launch (OvlConsumer below); null = the input is complete at launch
     const int* ovl_prog; int ovl_T, ovl_K, ovl_spin, ovl_base;
+#ifdef CHAIN_PAIR_GEOMETRY
+    // the exchange buffers and the flags of the pairs (flag [pair][sender][wave] = (pair_epoch * 16 + layers handed over) << 4 | XCC id)
+    float* exch; int* pflags; int pair_epoch, pair_spin;
+#endif
 };
 // rows per workgroup of a descriptor (32 RT GR; 256 for a constant band)
 __host__ __device__ inline int chain_rows(const ChainDesc& d) { return d.constant ? 256 : (d.RT >= 3 ? 16 * d.RT : 32 * d.RT * (8 / d.NW)); }   // RT >= 3: row tiles of 16 (16 x 16 x 32 geometry: 48 or 80 rows)

@@ -46,6 +46,7 @@ typedef const v4f __attribute__((address_space(1)))* gc4;
 typedef v4f __attribute__((address_space(1)))* g4;
 typedef const h8 __attribute__((address_space(1)))* gch8;
 typedef const char __attribute__((address_space(1)))* gcc;
+typedef unsigned u4x __attribute__((ext_vector_type(4)));
 
 #ifndef CHAIN_NO_RAG_CODE
 #define CHAIN_NO_RAG_CODE 0     // measurement only: compile the ragged-tile k-split out (register pressure probe)
@@ -797,13 +798,355 @@ __device__ __forceinline__ void chain_body48(const ChainLaunch& g, const ChainDe
     if (TERMS != -1 && amax > 65504.f && g.range_flag) *g.range_flag = 1;      // (bf16 has the range of fp32)
 }
 
+#ifdef CHAIN_PAIR_GEOMETRY
+// =====================================================================================
+// The widest band as PAIRS of workgroups (round 4): MEASURED AND NOT ADOPTED - compiled only with -DCHAIN_PAIR_GEOMETRY, which only
+// tools/chain_bench.hip does (tools/pair_probe.sh; numbers in profiles/r04_pair_geometry.txt, the reasons in DESIGN.md section 4c).  The fused chains are bound by the rate at which the chip moves weight fragments from
+// L2 into the CUs (9.3 TB/s aggregate, counter-backed: profiles/r04b_summary.md), and the 768-wide band streams 57 % of them because LDS
+// holds the fp16x2 image of only 48 of its rows.  Here two workgroups share 80 rows: workgroup `half` keeps half `half` of K of every
+// layer's input (80 x 384 x 4 B = 120 KB), multiplies it with ALL output features - its fragment stream is half the layer's weights -
+// and hands the partial sums of the PARTNER's half of the outputs over through L2; the partial sums of its own half it completes with
+// the partner's, and their epilogue (bias, LeakyReLU, split) writes exactly the half of K it holds of the next layer.  Weight bytes per row
+// of the band: / (80 / 48) -> - 40 %; + 2 x 120 KB of partial sums written and read per layer and pair.
+// Hand-over (cdna_hip_programming.md, Guideline 16): partial sums stored write-through (buffer_store_dwordx4 ... sc1), every wave drains,
+// workgroup barrier, one lane stores the sender's flag (pair_epoch * 16 + layers handed over, sc1); a receiving wave polls that flag with
+// relaxed agent-scope loads (bounded), one agent-scope acquire per wave and layer (the exchange buffers are reused every second layer: this
+// CU's L1 may hold their old lines), plain 16-byte loads.  The two workgroups of a pair are adjacent in the task table, so they are
+// dispatched together; a partner that never arrives is REPORTED (guard value 6: api.hip runs the call again with the unpaired geometry).
+// Geometry: five row tiles of 16 on v_mfma_f32_16x16x32_f16 (the 80-row body's), a wave's tiles = wn + 8 j of each half (three of each
+// for 768 features), the partner's half first.
+// =====================================================================================
+#ifndef CHAIN_PAIR_ABL
+#define CHAIN_PAIR_ABL 0      // measurement only: 1 no partial-sum stores, 2 no wait for / loads of the partner's, 4 no fragment loads in the K loop, 8 no LDS reads in it
+#endif
+#ifndef CHAIN_PAIR_LATE
+#define CHAIN_PAIR_LATE 1
+#endif
+#ifndef CHAIN_PAIR_TPS
+#define CHAIN_PAIR_TPS 1      // feature tiles per pass of the BandSplit chain in the paired geometry
+#endif
+#ifndef CHAIN_PAIR_PD
+#define CHAIN_PAIR_PD 2
+#endif
+#ifndef CHAIN_PAIR_TPM
+#define CHAIN_PAIR_TPM 1      // ... of the MaskEstimation chain
+#endif
+#ifndef CHAIN_PAIR_PDM
+#define CHAIN_PAIR_PDM 2
+#endif
+template <int CHAIN, int TERMS, int PDR = (CHAIN == CHAIN_SPLIT ? CHAIN_PAIR_PD : CHAIN_PAIR_PDM), int TP = (CHAIN == CHAIN_SPLIT ? CHAIN_PAIR_TPS : CHAIN_PAIR_TPM)>
+__device__ __forceinline__ void chain_body_pair(const ChainLaunch& g, const ChainDesc* const dp, const int row0, const int half, char* const smem)
+{
+    constexpr int RT = 5, CTR = 3;
+    constexpr int NPL = (TERMS == 1 || TERMS == -1) ? 1 : 2;
+    constexpr int NW = 8, ROWS = 16 * RT, UB = ROWS * 16;
+    float* const sbias = reinterpret_cast<float*>(smem + CHAIN_LDS_EX);
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, gq = lane >> 4;
+    const int M = g.M;
+    const int plane = dp->plane_units * UB;
+    float amax = 0.f;
+    // the pair's exchange buffers and flags
+    const int pid = dp->pair_base + row0 / ROWS;
+    float* const ex_send = g.exch + (size_t)(pid * 2 + half) * 2 * (ROWS * PAIR_NH);
+    float* const ex_recv = g.exch + (size_t)(pid * 2 + (half ^ 1)) * 2 * (ROWS * PAIR_NH);
+    typedef int __attribute__((address_space(1)))* gi;
+    const gi flag_send = (gi)(g.pflags + (pid * 2 + half) * NW + wn), flag_recv = (gi)(g.pflags + (pid * 2 + (half ^ 1)) * NW + wn);      // one per wave
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;               // HW_REG_XCC_ID[3:0]
+    const __amdgpu_buffer_rsrc_t send_rsrc = __builtin_amdgcn_make_buffer_rsrc(ex_send, 0, (int)(2 * ROWS * PAIR_NH * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t recv_rsrc = __builtin_amdgcn_make_buffer_rsrc(ex_recv, 0, (int)(2 * ROWS * PAIR_NH * sizeof(float)), 0x00020000);
+    bool timed_out = false, misplaced = false;
+
+    constexpr int STEP = NPL * 1024;
+    const gcc wbase = (gcc)dp->wstream;
+    const unsigned lane16 = lane * 16;
+    h8 w[PDR][TP][NPL];
+    auto wload = [&](int set, gcc p, int ks, int K32, bool two) {
+#pragma unroll
+        for (int tt = 0; tt < TP; ++tt) {
+            if (tt == 1 && !two) break;
+#pragma unroll
+            for (int pc = 0; pc < NPL; ++pc) w[set][tt][pc] = *(gch8)(p + (size_t)(tt * K32 + ks) * STEP + pc * 1024 + lane16);
+        }
+    };
+    // this wave's tiles of a layer: cnt of the partner's half, then cnt of its own; its stream starts behind those of the waves before it
+    auto layer_stream = [&](int l, int& K32, int& cnt, gcc& wp) {
+        K32 = dp->L[l].K16;
+        const int FTh = dp->L[l].NTL >> 1;
+        cnt = wn < FTh ? (FTh - wn + NW - 1) / NW : 0;
+        int before = 0;
+        for (int w8 = 0; w8 < wn; ++w8) before += w8 < FTh ? 2 * ((FTh - w8 + NW - 1) / NW) : 0;
+        wp = wbase + (half ? dp->L[l].w_off1 : dp->L[l].w_off) + (size_t)before * K32 * STEP;
+    };
+    auto prefetch_layer = [&](int l) {
+        int K32, cnt; gcc wp;
+        layer_stream(l, K32, cnt, wp);
+        if (cnt > 0) {
+#pragma unroll
+            for (int s = 0; s < PDR; ++s)
+                if (s < K32) wload(s, wp, s, K32, TP > 1 && cnt > 1);
+        }
+    };
+    prefetch_layer(0);
+
+    // ---- biases -> LDS; this workgroup's half of the input columns of the 80 rows -> LDS, split on the way
+    {
+        const gcf bsrc = (gcf)dp->bias;
+        const int nb = dp->nbias;
+        for (int i = tid; i < nb; i += 512) sbias[i] = bsrc[i];
+        const int U0 = 4 * dp->L[0].K16, K0h = dp->K0 >> 1;
+        for (int u0 = 2 * wn; u0 < U0; u0 += 2 * NW * 2) {
+            v4f v[RT][2];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                int rr = row0 + 16 * r + m;
+                rr = rr < M ? rr : M - 1;
+                const gcf xin = (gcf)g.Xin + (size_t)rr * g.ldx + dp->in_off + half * K0h;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int k = 8 * (u0 + 2 * NW * i + (gq >> 1)) + 4 * (gq & 1);
+                    v[r][i] = (v4f){0.f, 0.f, 0.f, 0.f};
+                    if (k < K0h) v[r][i] = *(gc4)(xin + k);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int u = u0 + 2 * NW * i + (gq >> 1);
+                    if (u >= U0) continue;
+                    const v4f x = v[r][i];
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
+                    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+                    h4 p0, p1;
+                    split4t<TERMS>(x, p0, p1);
+                    char* const d = smem + u * UB + (16 * r + m) * 16 + 8 * (gq & 1);
+                    *reinterpret_cast<h4*>(d) = p0;
+                    if (NPL == 2) *reinterpret_cast<h4*>(d + plane) = p1;
+                }
+        }
+    }
+    __syncthreads();
+
+    auto layer = [&](auto last_tag, const int l) {
+        constexpr bool last = decltype(last_tag)::value;
+        int rowl[RT];
+        bool rokl[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            int rr = row0 + 16 * r + m;
+            asm volatile("" : "+v"(rr));
+            rokl[r] = rr < M;
+            rowl[r] = rokl[r] ? rr : M - 1;
+        }
+        int K32, cnt; gcc wp;
+        layer_stream(l, K32, cnt, wp);
+        const int FTh = dp->L[l].NTL >> 1;
+        const int boff = dp->L[l].bias_off;
+        const bool leaky = dp->L[l].leaky != 0;
+        const bool to_p = CHAIN == CHAIN_SPLIT && l == 1;
+        const int par = l & 1;
+        int mx = m, gx = gq;                                     // (opaque per layer: the exchange / epilogue offsets are not worth registers across the K loops)
+        asm volatile("" : "+v"(mx), "+v"(gx));
+        h4 held[last ? 1 : CTR][RT][NPL];
+        v4f hi[TP][RT], lo[TP][RT];
+        // one pass over this half of K for the wave's tiles c, c + 1 of its stream (c counts the partner's tiles first, then its own)
+        auto kloop = [&](const int c, const bool two, const bool more, const bool more_two) {
+            const gcc tp = wp + (size_t)c * K32 * STEP;
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) { hi[tt][r] = (v4f){0.f, 0.f, 0.f, 0.f}; lo[tt][r] = hi[tt][r]; }
+            h8 bn[RT][NPL];
+            auto bload = [&](int ks) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int pc = 0; pc < NPL; ++pc)
+                        bn[r][pc] = *reinterpret_cast<const h8*>(smem + pc * plane + (4 * ks + gq) * UB + (16 * r + m) * 16);
+            };
+            bload(0);
+            auto compute = [&](int set, int ks) {
+#pragma unroll
+                for (int tt = 0; tt < TP; ++tt) {
+                    if (tt == 1 && !two) break;
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        if (NPL == 2) {
+                            lo[tt][r] = mfma16<TERMS>(w[set][tt][0], bn[r][NPL - 1], lo[tt][r]);
+                            lo[tt][r] = mfma16<TERMS>(w[set][tt][NPL - 1], bn[r][0], lo[tt][r]);
+                        }
+                        hi[tt][r] = mfma16<TERMS>(w[set][tt][0], bn[r][0], hi[tt][r]);
+                    }
+                }
+                if (!(CHAIN_PAIR_ABL & 8)) bload(ks + 1 < K32 ? ks + 1 : ks);
+            };
+            int ks0 = 0;
+            for (; ks0 + 2 * PDR <= K32; ks0 += PDR) {
+#pragma unroll
+                for (int s = 0; s < PDR; ++s) {
+                    compute(s, ks0 + s);
+                    if (!(CHAIN_PAIR_ABL & 4)) wload(s, tp, ks0 + s + PDR, K32, two);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            for (; ks0 < K32; ks0 += PDR) {
+#pragma unroll
+                for (int s = 0; s < PDR; ++s) {
+                    const int ks = ks0 + s;
+                    if (ks < K32) {
+                        compute(s, ks);
+                        if (ks + PDR < K32) wload(s, tp, ks + PDR, K32, two);
+                        else if (more && s < K32) wload(s, tp + (size_t)(two ? 2 : 1) * K32 * STEP, s, K32, more_two);      // the next pass
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (NPL == 2) {
+#pragma unroll
+                for (int tt = 0; tt < TP; ++tt)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) hi[tt][r] += (1.f / 2048.f) * lo[tt][r];
+            }
+        };
+        // ---- the partner's half of the outputs: raw partial sums -> the exchange buffer (write-through), rows as they come
+#pragma unroll 1
+        for (int c = 0; c < cnt; c += TP) {
+            const bool two = TP > 1 && c + 1 < cnt;
+            const int cn = c + (two ? 2 : 1);                                    // the next pass: more of the partner's tiles, or the first of its own
+            kloop(c, two, cnt > 0, TP > 1 && cn + 1 < 2 * cnt && (cn + 1 < cnt || cn >= cnt));
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt) {
+                if (tt == 1 && !two) break;
+                const int fl = 16 * (wn + NW * (c + tt)) + 4 * gx;               // feature inside the receiver's half
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (!(CHAIN_PAIR_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4x, hi[tt][r]), send_rsrc, ((par * ROWS + 16 * r + mx) * PAIR_NH + fl) * 4, 0, 0);
+                }
+            }
+        }
+        // wave wn's partial sums are what the partner's wave wn completes: the hand-over is wave to wave.  Through the XCD's L2, which both
+        // workgroups share (lstm.hip::band_pair_h2_kernel): a store is counted out of vmcnt when L2 has it; the flag carries the XCC id, so
+        // that a placement which breaks the assumption is reported.
+        auto hand_over = [&]() {
+        if (cnt > 0 && !(CHAIN_PAIR_ABL & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flag_send, ((g.pair_epoch * 16 + l + 1) << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int want = g.pair_epoch * 16 + l + 1;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int v;
+            while (((v = __hip_atomic_load(flag_recv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 4) - want < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)g.pair_spin) { timed_out = true; break; }
+            }
+            if (!timed_out && (v & 15) != xcc) misplaced = true;                  // the partner sits on another XCD
+            asm volatile("buffer_inv sc0" ::: "memory");                         // the partner's sums from L2, not from a line this CU's L1 may hold (the buffers are reused every second layer)
+        }
+        };
+        if (!CHAIN_PAIR_LATE) hand_over();
+        // ---- its own half: complete the partial sums with the partner's (requested in front of the K loop), then the usual epilogue
+#pragma unroll
+        for (int c0 = 0; c0 < CTR; c0 += TP) {
+            if (c0 >= cnt) break;
+            const int c = cnt + c0;
+            const bool two = TP > 1 && c0 + 1 < cnt;
+            const bool more = c0 + (two ? 2 : 1) < cnt;
+            v4f pp[TP][RT];
+            auto load_pp = [&]() {
+#pragma unroll
+                for (int tt = 0; tt < TP; ++tt) {
+                    if (tt == 1 && !two) break;
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+                        pp[tt][r] = (CHAIN_PAIR_ABL & 2) ? (v4f){0.f, 0.f, 0.f, 0.f}
+                            : __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(recv_rsrc, ((par * ROWS + 16 * r + mx) * PAIR_NH + 16 * (wn + NW * (c0 + tt)) + 4 * gx) * 4, 0, 0));
+                }
+            };
+            // CHAIN_PAIR_LATE: the hand-over (drain, flag, wait for the partner's) behind the K loop of the first pass of the own half - the
+            // stores have long been counted out then and the partner's flag is there; its sums for this pass are requested late, once
+            if (!CHAIN_PAIR_LATE || c0 > 0) load_pp();
+            kloop(c, two, more, TP > 1 && c0 + (two ? 2 : 1) + 1 < cnt);
+            if (CHAIN_PAIR_LATE && c0 == 0) { hand_over(); load_pp(); }
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt) {
+                if (tt == 1 && !two) break;
+                const int tl = wn + NW * (c0 + tt);                              // tile inside this half
+                const int n0 = 16 * (half * FTh + tl) + 4 * gx;                  // first of this lane's 4 consecutive features
+                const v4f bv = *reinterpret_cast<const v4f*>(&sbias[boff + n0]);
+                v4f rv[RT], mv[RT];                                              // the mask chain's last layer: residual P and the spectrum
+                if (CHAIN == CHAIN_MASK && last) {
+                    const int nn = n0 < dp->a8 ? n0 : 0;
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        rv[r] = *(gc4)((gcf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + nn);
+                        mv[r] = *(gc4)((gcf)g.Xmul + (size_t)rowl[r] * g.ldm + dp->p_off + nn);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float own = hi[tt][r][e];
+                        // (lower half of K + upper half of K, whichever workgroup adds: both halves of a pair produce the same bits)
+                        v[e] = (half ? pp[tt][r][e] + own : own + pp[tt][r][e]) + bv[e];
+                        if (leaky) v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                    }
+                    if (!last) {
+                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+                        h4 p0, p1;
+                        split4t<TERMS>(v, p0, p1);
+                        held[last ? 0 : c0 + tt][r][0] = p0;
+                        held[last ? 0 : c0 + tt][r][NPL - 1] = NPL == 2 ? p1 : p0;
+                        if (to_p && rokl[r] && n0 < dp->a8) *(g4)((gf)g.P + (size_t)rowl[r] * g.ldp + dp->p_off + n0) = v;
+                    } else if (CHAIN == CHAIN_SPLIT) {
+                        if (rokl[r] && n0 < HID) *(g4)((gf)g.Z + (size_t)rowl[r] * g.ldz + dp->z_off + n0) = v;
+                    } else {
+                        if (rokl[r] && n0 < dp->a8) {
+                            v += rv[r];
+                            if (g.tap) *(g4)((gf)g.tap + (size_t)rowl[r] * g.ldt + dp->p_off + n0) = v;
+                            *(g4)((gf)g.Y + (size_t)rowl[r] * g.ldy + dp->p_off + n0) = v * mv[r];
+                        }
+                    }
+                }
+            }
+        }
+        if (last) return;
+        prefetch_layer(l + 1);
+        __syncthreads();                                         // every wave has read the layer's input image
+#pragma unroll
+        for (int c = 0; c < CTR; ++c) {
+            if (c >= cnt) break;
+            const int tl = wn + NW * c;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                char* const d = smem + (2 * tl + (gx >> 1)) * UB + (16 * r + mx) * 16 + 8 * (gx & 1);
+                *reinterpret_cast<h4*>(d) = held[last ? 0 : c][r][0];
+                if (NPL == 2) *reinterpret_cast<h4*>(d + plane) = held[last ? 0 : c][r][NPL - 1];
+            }
+        }
+        __syncthreads();                                         // the next layer's input image (this half of its K) is complete
+    };
+#pragma unroll 1
+    for (int l = 0; l < CHAIN_LAYERS - 1; ++l) layer(std::false_type(), l);
+    layer(std::true_type(), CHAIN_LAYERS - 1);
+    if (TERMS != -1 && amax > 65504.f && g.range_flag) *g.range_flag = 1;
+    if ((timed_out || misplaced) && g.range_flag) *g.range_flag = timed_out ? 6 : 7;      // the partner never arrived / sits on another XCD: reported, the numbers are not used
+}
+
+#endif      // CHAIN_PAIR_GEOMETRY
+
 template <int CHAIN, int TERMS>
 __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
 {
     __shared__ __attribute__((aligned(16))) char smem[CHAIN_LDS_EX + CHAIN_LDS_BIAS];
 
     const int2 task = g.tasks[blockIdx.x];
-    const int di = task.x, row0 = task.y;
+    const int di = task.x & 0xffffff, row0 = task.y;      // (bits 24+: the probe-only paired geometry's half)
     const ChainDesc* const dp = g.desc + di;
     if (CHAIN == CHAIN_MASK && g.ovl_prog) {
         // launched beside the time-axis launch that writes the chain's input (kernels.h, OvlConsumer): wait until the frames of this
@@ -833,6 +1176,9 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
     // geometry of the workgroup (wave-uniform): 48 rows on 16 x 16 tiles, or rows = 32 RT GR on 32 x 32 tiles
     const int RT = dp->RT, GR = 8 / dp->NW;
 #ifdef CHAIN_ONLY_BODY            // measurement only: compile ONE geometry (register / scratch use per body: tools/kernel_resources.py)
+#ifdef CHAIN_PAIR_GEOMETRY
+    if (CHAIN_ONLY_BODY == 7) { chain_body_pair<CHAIN, TERMS>(g, dp, row0, (task.x >> 24) & 1, smem); return; }
+#endif
     if (CHAIN_ONLY_BODY == 6) chain_body48<CHAIN, TERMS, 4, 5, CHAIN_PD64, CHAIN_TP64, true>(g, dp, row0, smem);
     else if (CHAIN_ONLY_BODY == 0) chain_body48<CHAIN, TERMS>(g, dp, row0, smem);
     else if (CHAIN_ONLY_BODY == 1) chain_body<CHAIN, TERMS, 1, 8>(g, dp, row0, smem);
@@ -845,6 +1191,9 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
 #endif
     // (every geometry ends in `return`: with an else-if chain and one join the structurizer lays the bodies out one behind the other
     //  and keeps values of the later ones - the thread index, for one - alive through the earlier ones' loops: spills at 256 VGPRs)
+#ifdef CHAIN_PAIR_GEOMETRY
+    if (dp->pair) { chain_body_pair<CHAIN, TERMS>(g, dp, row0, (task.x >> 24) & 1, smem); return; }
+#endif
     if (RT == 3) { chain_body48<CHAIN, TERMS>(g, dp, row0, smem); return; }
     if (RT == 5) { chain_body48<CHAIN, TERMS, 5, 3, 2, (CHAIN == CHAIN_SPLIT ? 1 : 2)>(g, dp, row0, smem); return; }
     if (RT == 4) { chain_body48<CHAIN, TERMS, 4, 5, CHAIN_PD64, CHAIN_TP64, true>(g, dp, row0, smem); return; }

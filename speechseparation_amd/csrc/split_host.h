@@ -134,6 +134,29 @@ inline void pack_chain_layer16_host(const float* w, int N, int K, int ldw, int N
                         }
 }
 
+// Paired geometry (mlp_chain.hip::chain_body_pair, probe only: tools/chain_bench.hip): the stream of the workgroup that holds K-half `half` of the layer input.  Wave wn of 8
+// walks, k-step by k-step over ITS half of K, first the feature tiles of the PARTNER's half of the outputs ((1 - half) FT / 2 + wn + 8 j),
+// then the tiles of its own half (half FT / 2 + wn + 8 j).  N and K multiples of 64.
+inline void pack_chain_layer16_pair_host(const float* w, int N, int K, int ldw, int half, int npl, std::vector<uint16_t>& out, bool bf = false)
+{
+    const int K32h = K / 64, FT = N / 16, FTh = FT / 2, k0 = half * (K / 2);
+    for (int wn = 0; wn < 8; ++wn)
+        for (int own = 0; own < 2; ++own)
+            for (int j = 0; wn + 8 * j < FTh; ++j) {
+                const int t = (own ? half : 1 - half) * FTh + wn + 8 * j;
+                for (int ks = 0; ks < K32h; ++ks)
+                    for (int pc = 0; pc < npl; ++pc)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int n = 16 * t + (l & 15), k = k0 + 32 * ks + 8 * (l >> 4) + e;
+                                const float v = w[(size_t)n * ldw + k];
+                                uint16_t p[2];
+                                split_planes_host(&v, 1, 2, p);
+                                out.push_back(bf ? bf16_from_float(v) : p[pc]);
+                            }
+            }
+}
+
 inline float join_planes_host(const uint16_t* planes, size_t n, size_t i, int np)
 {
     if (np == 3) return (bf16_to_float(planes[i]) + bf16_to_float(planes[n + i])) + bf16_to_float(planes[2 * n + i]);

@@ -3,6 +3,7 @@
 // be read in isolation (one round of workgroups = the duration of one workgroup).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize [-DCHAIN_PD=8 -DCHAIN_ABL=0] -o build/chain_bench tools/chain_bench.hip
 //   build/chain_bench [M=8064] [chain: 0 split | 1 mask] [bands: e.g. 9 or 9,10 or all]
+#define CHAIN_PAIR_GEOMETRY 1      // the paired geometry of the widest band exists only in this probe (CHAIN_PAIR=1)
 #include "../speechseparation_amd/csrc/mlp_chain.hip"
 #include "../speechseparation_amd/csrc/split_host.h"
 
@@ -79,15 +80,18 @@ int main(int argc, char** argv)
             try80 = 2 * u * 80 * 16 <= CHAIN_LDS_EX && maxft <= 24 && whole && maxft % 8 == 0;
             try64 = was80 && !try80 && !getenv("BSRNN_CHAIN_NO64") && 2 * u * 64 * 16 <= CHAIN_LDS_EX && maxft <= 40;      // as api.hip: four row tiles of 16
         }
-        const bool g48 = try48 || try80 || try64;
+        const bool pair = getenv("CHAIN_PAIR") && a == 768;        // two workgroups per 80 rows, half of K each (chain_body_pair)
+        const bool g48 = try48 || try80 || try64 || pair;
         if (g48) {
-            RT = try48 ? 3 : (try64 ? 4 : 5); GR = 1; units = 0; nbias = 0;
+            RT = pair ? 5 : (try48 ? 3 : (try64 ? 4 : 5)); GR = 1; units = 0; nbias = 0;
             for (int l = 0; l < 5; ++l) {
                 const int N = chain ? dims_m[l][0] : dims_s[l][0], Kd = chain ? dims_m[l][1] : dims_s[l][1];
                 d.L[l].K16 = (Kd + 31) / 32; d.L[l].NTL = (N + 15) / 16; d.L[l].bias_off = nbias; nbias += 16 * d.L[l].NTL;
+                if (pair) d.L[l].K16 = Kd / 64;
                 units = std::max(units, 4 * d.L[l].K16);
-                if (l < 4) units = std::max(units, 2 * d.L[l].NTL);
+                if (l < 4) units = std::max(units, (pair ? 1 : 2) * d.L[l].NTL);
             }
+            d.pair = pair; d.pair_base = 0;
         }
         d.RT = RT; d.NW = 8 / GR; d.plane_units = units; d.nbias = nbias;
         d.in_off = chain ? i * H : poff[i]; d.K0 = chain ? H : d.a8;
@@ -102,11 +106,15 @@ int main(int argc, char** argv)
             std::vector<float> w((size_t)N * Kd);
             for (auto& x : w) x = frand(seed) / sqrtf((float)Kd);
             d.L[l].w_off = (unsigned)(bu.w.size() * 2);
-            if (g48) pack_chain_layer16_host(w.data(), N, Kd, Kd, 8, 2, bu.w);
+            if (pair) {
+                pack_chain_layer16_pair_host(w.data(), N, Kd, Kd, 0, 2, bu.w);
+                d.L[l].w_off1 = (unsigned)(bu.w.size() * 2);
+                pack_chain_layer16_pair_host(w.data(), N, Kd, Kd, 1, 2, bu.w);
+            } else if (g48) pack_chain_layer16_host(w.data(), N, Kd, Kd, 8, 2, bu.w);
             else pack_chain_layer_host(w.data(), N, Kd, Kd, d.NW, 2, bu.w, d.L[l].rag);
             for (int n = 0; n < N; ++n) bu.b[d.L[l].bias_off + n] = 0.1f * frand(seed);
         }
-        wbytes_per_tile += g48 ? bu.w.size() * 2 * 32 / (16 * d.RT) : bu.w.size() * 2 / d.RT;      // per 32 rows: a wave group streams the weights once for its rows
+        wbytes_per_tile += pair ? bu.w.size() * 32 / 80 : g48 ? bu.w.size() * 2 * 32 / (16 * d.RT) : bu.w.size() * 2 / d.RT;      // per 32 rows: a wave group streams the weights once for its rows
         printf("band %2d a=%4d  NW=%d RT=%d  units=%3d  weights %.2f MB  cost %ld\n", i, a, d.NW, d.RT, units, bu.w.size() * 2 / 1e6, bu.cost);
         built.push_back(std::move(bu));
     }
@@ -142,8 +150,9 @@ int main(int argc, char** argv)
     double ww = 0, wr = 0;
     for (size_t di = 0; di < descs.size(); ++di)
         for (int r0 = 0; r0 < M; r0 += chain_rows(descs[di])) {
-            const bool w = chain_rows(descs[di]) <= 48;
+            const bool w = chain_rows(descs[di]) <= 48 || descs[di].pair;
             (w ? wide : rest).push_back(make_int2((int)di, r0));
+            if (descs[di].pair) wide.push_back(make_int2((int)di | 1 << 24, r0));       // the partner: adjacent in the table
             (w ? ww : wr) += (double)built[di].cost * descs[di].RT + 200.0;
         }
     if (getenv("CHAIN_ORDER") && !strcmp(getenv("CHAIN_ORDER"), "mix")) {
@@ -176,6 +185,21 @@ int main(int argc, char** argv)
     } else {
         tasks = wide; tasks.insert(tasks.end(), rest.begin(), rest.end());
     }
+    if (!getenv("CHAIN_PAIR_ADJ")) {
+        // partners 8 workgroup ids apart (the same XCD): groups of 8 pairs, lower halves then upper halves; a last group of fewer pairs is
+        // filled up with other bands' workgroups (none left: the group's pairs sit on different XCDs and the launch says so)
+        std::vector<int2> pt, other;
+        for (const int2& t : tasks) (descs[t.x & 0xffffff].pair ? pt : other).push_back(t);
+        tasks.clear();
+        size_t o = 0;
+        for (size_t i = 0; i < pt.size(); i += 16) {
+            const size_t n = std::min<size_t>(16, pt.size() - i);
+            for (size_t k = 0; k < n; k += 2) tasks.push_back(pt[i + k]);
+            for (size_t k = n / 2; k < 8 && o < other.size(); ++k) tasks.push_back(other[o++]);
+            for (size_t k = 1; k < n; k += 2) tasks.push_back(pt[i + k]);
+        }
+        tasks.insert(tasks.end(), other.begin() + o, other.end());
+    }
     int2* dtasks;
     CK(hipMalloc(&dtasks, tasks.size() * sizeof(int2)));
     CK(hipMemcpy(dtasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice));
@@ -183,15 +207,22 @@ int main(int argc, char** argv)
     g.desc = dd; g.M = M;
     if (chain == 0) { g.Xin = X; g.ldx = LDP; g.P = P; g.ldp = LDP; g.Z = Z; g.ldz = KH; }
     else { g.Xin = Z; g.ldx = KH; g.P = P; g.ldp = LDP; g.Xmul = X; g.ldm = LDP; g.Y = Y; g.ldy = LDP; }
+    {
+        const int pairs = (M + PAIR_ROWS - 1) / PAIR_ROWS;
+        CK(hipMalloc(&g.exch, pairs * PAIR_EXCH_FLOATS * sizeof(float)));
+        CK(hipMalloc(&g.pflags, pairs * 16 * sizeof(int))); CK(hipMemset(g.pflags, 0, pairs * 16 * sizeof(int)));
+        g.pair_epoch = 0; g.pair_spin = 20000000;
+        int* rf; CK(hipMalloc(&rf, 4)); CK(hipMemset(rf, 0, 4)); g.range_flag = rf;
+    }
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) launch_mlp_chain(g, chain, s);
+    for (int i = 0; i < 20; ++i) { ++g.pair_epoch; launch_mlp_chain(g, chain, s); }
     CK(hipStreamSynchronize(s));
     const int reps = 50;
     CK(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i) launch_mlp_chain(g, chain, s);
+    for (int i = 0; i < reps; ++i) { ++g.pair_epoch; launch_mlp_chain(g, chain, s); }
     CK(hipEventRecord(e1, s));
     CK(hipStreamSynchronize(s));
     float ms;
@@ -221,6 +252,15 @@ int main(int argc, char** argv)
             const unsigned long long* d0 = &h[(size_t)blk * 8 * 24];
             printf("  total (wave 0) %.2f us\n", (d0[15] - d0[0]) * 0.01);
         }
+    }
+    {
+        // checksum of the outputs of the last launch and the guard word (compare CHAIN_PAIR=1 with the unpaired geometry: same sums up to rounding)
+        int rfh = 0; CK(hipMemcpy(&rfh, g.range_flag, 4, hipMemcpyDeviceToHost));
+        std::vector<float> ho(chain ? hx.size() : hz.size());
+        CK(hipMemcpy(ho.data(), chain ? Y : Z, ho.size() * 4, hipMemcpyDeviceToHost));
+        double sum = 0, sa = 0; for (float v : ho) { sum += v; sa += fabs(v); }
+        printf("guard %d  output sum %.9g  sum|.| %.9g\n", rfh, sum, sa);
+        if (getenv("CHAIN_DUMP")) { FILE* f = fopen(getenv("CHAIN_DUMP"), "wb"); fwrite(ho.data(), 4, ho.size(), f); fclose(f); }
     }
     printf("chain %d  M %d  bands %s  PD %d ABL %d:  %d blocks  %.1f us  %.1f TFLOP/s-equivalent  weight stream %.2f GB -> %.2f TB/s\n", chain, M, sel.c_str(),
            CHAIN_PD, CHAIN_ABL, g.n_tasks, us, flop / us / 1e6, wbytes_per_tile * ((M + 31) / 32) / 1e9, wbytes_per_tile * ((M + 31) / 32) / us / 1e6);
