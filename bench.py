@@ -227,7 +227,7 @@ def exact_f32_record(args):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, args.steps // 2)), "--warmup", str(args.warmup),
-           "--rows", str(args.rows), "--samples", str(args.samples), "--no-cpu-baseline", "--no-exact-f32", "--no-train-step"]
+           "--rows", str(args.rows), "--samples", str(args.samples), "--no-cpu-baseline", "--no-exact-f32", "--no-train-step", "--no-in-flight"]
     try:
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
@@ -295,6 +295,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-fp32 sub-record (a child process)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step sub-record (a child process)")
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the two / three batches in flight report item")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with no launcher: become the launcher (N rank processes), before any GPU call
@@ -423,6 +424,36 @@ def main():
                 os.environ.pop("BSRNN_OVERLAP", None)
             else:
                 os.environ["BSRNN_OVERLAP"] = keep
+    # Two and three independent batches in flight: further contexts (same weights, same input, own outputs) on streams of their own, the
+    # calls alternating - how a server with more than one request queue would drive the library.  A report item beside `value` (which is
+    # ONE context on ONE stream): launches of different batches fill each other's tails and the CUs a time-axis launch leaves idle.
+    in_flight = None
+    if world == 1 and not args.no_in_flight:
+        ctxs = [model] + [build_model(device)[0] for _ in range(2)]
+        strs = [torch.cuda.current_stream(device)] + [torch.cuda.Stream(device) for _ in range(2)]
+        outs = [out] + [torch.empty_like(out) for _ in range(2)]
+        for m_ in ctxs[1:]:
+            m_.set_range_policy("deferred")
+        in_flight = {}
+        for nctx in (2, 3):
+            def loop(k):
+                for i in range(k):
+                    j = i % nctx
+                    with torch.cuda.stream(strs[j]):
+                        ctxs[j].separate(wave, out=outs[j])
+            loop(12 * nctx)
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            n_if = max(30, args.steps)
+            loop(n_if)
+            torch.cuda.synchronize()
+            ms_if = 1e3 * (time.perf_counter() - tq) / n_if
+            for j in range(nctx):
+                with torch.cuda.stream(strs[j]):
+                    ctxs[j].sync()                # (raises on a range-guard violation)
+            in_flight[str(nctx)] = {"ms_per_step": round(ms_if, 4), "row_frames_per_s": round((hi - lo) * T / (ms_if * 1e-3), 1), "steps": n_if,
+                                    "outputs_equal": bool(all(torch.equal(outs[0], o) for o in outs[1:nctx]))}
+        del ctxs, outs
     # the reference's own operator on the same batch: BSRNN.forward on [R, 2050, T] (two layout transposes that `separate`
     # does not pay, no STFT / iSTFT) - a report item beside `value`
     xspec = model.stft(wave)
@@ -551,6 +582,9 @@ def main():
             line["stages_note"] = ("`stages` and `roofline_dual_path` are the launches one after the other (second context, BSRNN_OVERLAP=0: %.4f ms per step); "
                                    "in the overlapped flow that `value` measures a consumer launch's bracket contains its waits" % alone["ms_per_step"])
             line["stages_overlapped_flow_ms"] = stages_overlapped
+        if in_flight is not None:
+            line["batches_in_flight"] = dict(in_flight, note="NOT `value`: the same step for 2 / 3 independent batches of %d rows in flight (one context and stream "
+                                             "each, calls alternating; ms per step = per batch); `value` is one context on one stream" % (hi - lo))
         if f32_rec is not None:
             line["exact_f32"] = f32_rec
         if train_rec is not None:

@@ -7,7 +7,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for kv in "$@"; do export "$kv"; done
 rm -rf gpurun_out/prof_$tag
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-train-step > gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-train-step --no-in-flight > gpurun_out/prof_$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, sys
 tag = sys.argv[1]

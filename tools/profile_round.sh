@@ -4,7 +4,7 @@
 set -e
 tag=$1
 export TMPDIR=/tmp
-B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-train-step"
+B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-exact-f32 --no-train-step --no-in-flight"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- $B > gpurun_out/prof_$tag.log 2>&1
 # counter passes serialise the kernels: the overlapped dual path (a consumer launch BESIDE its producer) cannot exist under them and would
 # only fall back after its bounded waits; the passes run the launches one after the other from the start
