@@ -5,8 +5,13 @@ GEMM / LSTM launches: 4-20 of 20 runs wrong), never alone, and never when their 
 claimed: 0 of 80 runs wrong with the same vectorised code).  Forced-zero wait counts do not change it, LDS guard bands do not,
 scalar fp32 code does not show it.  The victims were kernels that issue no MFMA of their own; the kernels that do (GEMM, chains,
 LSTMs) run hand-written packed fp32 beside MFMA waves all the time and stay bit-stable beside other kernels (tests/test_gpu_coresident.py).
-The library is therefore built without the SLP vectorizer, and this test holds the rule the evidence supports on the code that
-ships: a kernel that issues no MFMA contains no packed-fp32 instruction at all."""
+Round 4 bisected the real kernels by instruction class (profiles/r04_vpk_bisect.txt: classes of packed instructions of the SLP listing
+rewritten in place into scalar pairs, schedule kept): what goes wrong is v_pk_add_f32 / v_pk_mul_f32 with a non-default `op_sel` - a low
+result lane reading the HIGH dword of a source pair, the crosswise reads of complex butterflies; plain forms, neg_lo / neg_hi,
+op_sel_hi alone, every v_pk_fma_f32 form and v_pk_mov_b32 were clean in 60-120 runs each.
+The library is therefore built without the SLP vectorizer, and this test holds two rules on the code that ships: a kernel that
+issues no MFMA contains no packed-fp32 instruction at all (the rule of rounds 2-3, kept), and NO kernel contains a v_pk_add_f32 /
+v_pk_mul_f32 with an op_sel modifier (the hand-written packed code of the MFMA kernels uses no modifier or op_sel_hi only)."""
 import os
 import re
 import struct
@@ -55,12 +60,15 @@ def test_packed_fp32_only_in_kernels_that_issue_mfma(tmp_path):
             m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
             if m:
                 cur = m.group(1)
-                stats[cur] = [0, 0]
+                stats[cur] = [0, 0, 0]
             elif cur is not None:
                 stats[cur][0] += "v_mfma" in ln
                 stats[cur][1] += bool(re.search(r"\bv_pk_(add|mul|fma)_f32\b|\bv_pk_mov_b32\b", ln))
-        bad = sorted(k for k, (mfma, pk) in stats.items() if pk and not mfma)
+                stats[cur][2] += bool(re.search(r"\bv_pk_(add|mul)_f32\b.*\bop_sel:\[", ln))
+        bad = sorted(k for k, (mfma, pk, sel) in stats.items() if pk and not mfma)
         assert not bad, "packed fp32 in kernels without MFMA (%s): %s" % (triple, bad[:5])
+        crosswise = sorted(k for k, (mfma, pk, sel) in stats.items() if sel)
+        assert not crosswise, "v_pk_add_f32 / v_pk_mul_f32 with op_sel (crosswise read: profiles/r04_vpk_bisect.txt) in (%s): %s" % (triple, crosswise[:5])
         n_kernels += len(stats)
         n_pk += sum(1 for v in stats.values() if v[1])
     # the disassembly worked: the DSP kernels are there, and the GEMM split / LSTM cells do use packed fp32
