@@ -105,3 +105,33 @@ def test_a_consumer_that_gives_up_is_reported_and_the_call_falls_back(sd_hot):
         bad2.separate(w)
     assert bad2.overlap_state() == 2
     assert np.array_equal(bad2.separate(w).cpu().numpy(), ref)
+
+
+def test_batches_in_flight_on_contexts_of_their_own_equal_one_after_the_other(sd_hot):
+    """Two and three independent contexts, each on a stream of its own, `separate()` calls alternating without a host wait between them
+    (bench.py's `batches_in_flight`; how a server with several request queues drives the C ABI): every kernel of one batch then runs beside
+    kernels of another - the overlapped dual path's progress words, gates and auxiliary streams included, all of which are per context.
+    Every output equals the same call made alone."""
+    from speechseparation_amd import weights
+    ctxs = [make_model(sd_hot, None) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    waves = [torch.from_numpy(weights.synth_waveform(64, 128000, seed=40 + j)).cuda() for j in range(3)]
+    refs = [ctxs[0].separate(w).clone() for w in waves]            # one context, one stream, one call at a time
+    torch.cuda.synchronize()
+    for m in ctxs:
+        m.set_range_policy("deferred")
+    outs = [torch.empty_like(refs[0]) for _ in range(3)]
+    for n in (2, 3):
+        for rep in range(8):
+            for j in range(n):
+                with torch.cuda.stream(streams[j]):
+                    ctxs[j].separate(waves[j], out=outs[j])
+            if rep % 4 == 3:
+                torch.cuda.synchronize()
+                for j in range(n):
+                    assert torch.equal(outs[j], refs[j]), "contexts in flight %d, round %d, context %d" % (n, rep, j)
+                    outs[j].zero_()
+    for j, m in enumerate(ctxs):
+        with torch.cuda.stream(streams[j]):
+            m.sync()                                                  # (raises on a guard word left set)
+        assert m.overlap_state() == 1
