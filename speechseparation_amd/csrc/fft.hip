@@ -10,7 +10,6 @@
 #include <type_traits>
 
 #include <cstdlib>
-#include <cstring>
 
 namespace bsrnn {
 
@@ -72,42 +71,6 @@ __device__ __forceinline__ float2* fft1024(float2* z0, float2* z1, const Twiddle
         float2* tmp = src; src = dst; dst = tmp;
     }
     return src;
-}
-
-// The same five passes for TWO independent transforms at once (a0 -> result in the returned buffer of the A pair, b likewise at the same parity):
-// one barrier per pass for both, and each thread's two butterflies are independent instruction streams.  Why: the offline kernels are chains of
-// latencies, not of bytes - with the passes, the stores or the loads compiled out the STFT's 35 us go to 26.5 / 29.5 / 32 us, with all three to
-// 10 us (NOTEBOOK R4.6) -, and four workgroups per CU is what the registers allow, so a workgroup keeps two frames in flight instead of one.
-template <bool INV>
-__device__ __forceinline__ int fft1024x2(float2* a0, float2* a1, float2* b0, float2* b1, const Twiddles& twd, int tid)
-{
-    float2 *sa = a0, *da = a1, *sb = b0, *db = b1;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int p = 1 << (2 * q);
-        const int k = tid & (p - 1);
-        const int jo = ((tid - k) << 2) + k;
-        float2 u0 = sa[tid], u1 = sa[tid + 256], u2 = sa[tid + 512], u3 = sa[tid + 768];
-        float2 w0 = sb[tid], w1 = sb[tid + 256], w2 = sb[tid + 512], w3 = sb[tid + 768];
-        if (q > 0) {
-            u1 = cmul(u1, twd.t[q - 1][0]); u2 = cmul(u2, twd.t[q - 1][1]); u3 = cmul(u3, twd.t[q - 1][2]);
-            w1 = cmul(w1, twd.t[q - 1][0]); w2 = cmul(w2, twd.t[q - 1][1]); w3 = cmul(w3, twd.t[q - 1][2]);
-        }
-        {
-            const float2 v0 = cadd(u0, u2), v1 = csub(u0, u2), v2 = cadd(u1, u3), d = csub(u1, u3);
-            const float2 v3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
-            da[jo] = cadd(v0, v2); da[jo + p] = cadd(v1, v3); da[jo + 2 * p] = csub(v0, v2); da[jo + 3 * p] = csub(v1, v3);
-        }
-        {
-            const float2 v0 = cadd(w0, w2), v1 = csub(w0, w2), v2 = cadd(w1, w3), d = csub(w1, w3);
-            const float2 v3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
-            db[jo] = cadd(v0, v2); db[jo + p] = cadd(v1, v3); db[jo + 2 * p] = csub(v0, v2); db[jo + 3 * p] = csub(v1, v3);
-        }
-        __syncthreads();
-        float2* t = sa; sa = da; da = t;
-        t = sb; sb = db; db = t;
-    }
-    return 1;             // five passes: the results are in a1 / b1
 }
 
 // Per-thread slice of the real-FFT split/merge step: bins k = tid + 256 i.  The column map and the
@@ -281,92 +244,8 @@ __global__ __launch_bounds__(256, FFT_OCC_STFT) void stft_kernel(FftTables tb, c
     }
 }
 
-// Two frames per pass of the loop (fft1024x2): frames t and t + 1 share the half between them, so an iteration loads two new halves - the same
-// bytes per frame as above - and stores two rows.  An odd last frame is transformed twice (the second copy stores the same values to the same row:
-// no branch around a store, see rfft_split_store).  The arithmetic of a frame is the one-frame kernel's, instruction for instruction: same results.
-template <bool ZERO_PAD>
-__global__ __launch_bounds__(256, FFT_OCC_STFT) void stft2_kernel(FftTables tb, const float* __restrict__ wave, float* __restrict__ X,
-                                                    int64_t n, int T, int sch)
-{
-    __shared__ __attribute__((aligned(16))) float2 za0[1024], za1[1024], zb0[1024], zb1[1024];
-    const int tid = threadIdx.x;
-    const Twiddles twd = load_twiddles<false>(tb.tw1024, tid);
-    const SplitCtx spl = load_split(tb, tid, false);
-    const int r = blockIdx.y;
-    const int t0 = blockIdx.x * sch;
-    const int t1 = (t0 + sch < T) ? t0 + sch : T;
-    const float* src = wave + (size_t)r * n;
-    float2 win[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) win[k] = make_float2(tb.hann[2 * (tid + 256 * k)], tb.hann[2 * (tid + 256 * k) + 1]);
-    auto sample2 = [&](int t, int c) {
-        float v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int64_t idx = (int64_t)t * HOPS + 2 * c + e - NFFT / 2;
-            if (ZERO_PAD) {
-                v[e] = (idx >= 0 && idx < n) ? src[idx] : 0.f;
-                continue;
-            }
-            if (idx < 0) idx = -idx;
-            if (idx >= n) idx = 2 * (n - 1) - idx;
-            v[e] = src[idx];
-        }
-        return make_float2(v[0], v[1]);
-    };
-    // h0 | h1 = frame t, h1 | h2 = frame t + 1 (halves of 512 complex samples: this thread's c and c + 256 of each)
-    float2 h0[2], h1[2], h2[2];
-    const int last = t1 - 1;
-    h0[0] = sample2(t0, tid); h0[1] = sample2(t0, tid + 256);
-    h1[0] = sample2(t0, tid + 512); h1[1] = sample2(t0, tid + 768);
-    { const int tb1 = t0 + 1 < t1 ? t0 + 1 : last; h2[0] = sample2(tb1, tid + 512); h2[1] = sample2(tb1, tid + 768); }
-    for (int t = t0; t < t1; t += 2) {
-        const int tB = t + 1 < t1 ? t + 1 : last;            // (== t for an odd last frame: its h2 was loaded as frame t's own second half)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            za0[tid + 256 * k] = make_float2(h0[k].x * win[k].x, h0[k].y * win[k].y);
-            za0[tid + 512 + 256 * k] = make_float2(h1[k].x * win[k + 2].x, h1[k].y * win[k + 2].y);
-        }
-        if (tB != t) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                zb0[tid + 256 * k] = make_float2(h1[k].x * win[k].x, h1[k].y * win[k].y);
-                zb0[tid + 512 + 256 * k] = make_float2(h2[k].x * win[k + 2].x, h2[k].y * win[k + 2].y);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                zb0[tid + 256 * k] = make_float2(h0[k].x * win[k].x, h0[k].y * win[k].y);
-                zb0[tid + 512 + 256 * k] = make_float2(h1[k].x * win[k + 2].x, h1[k].y * win[k + 2].y);
-            }
-        }
-        __syncthreads();
-        // the next pair: frame t + 2 = h2 | new, frame t + 3 = new | new (requested before the passes; past the chunk: dummy reloads)
-        h0[0] = h2[0]; h0[1] = h2[1];
-        { const int ta = t + 2 < t1 ? t + 2 : last; h1[0] = sample2(ta, tid + 512); h1[1] = sample2(ta, tid + 768); }
-        { const int tb2 = t + 3 < t1 ? t + 3 : last; h2[0] = sample2(tb2, tid + 512); h2[1] = sample2(tb2, tid + 768); }
-        fft1024x2<false>(za0, za1, zb0, zb1, twd, tid);
-        rfft_split_store(za1, spl, X + ((size_t)r * T + t) * tb.ld, tid);
-        rfft_split_store(zb1, spl, X + ((size_t)r * T + tB) * tb.ld, tid);
-        __syncthreads();                          // za1 / zb1 are overwritten by the next pair's first pass (za0 / zb0 by its staging: behind this barrier too)
-    }
-}
-
-static bool fft_two_frames()
-{
-    static const bool on = [] { const char* e = getenv("BSRNN_FFT_TWO"); return !(e && !strcmp(e, "0")); }();      // A/B: 0 = one frame per pass of the loop
-    return on;
-}
-
 void launch_stft(const FftTables& tb, const float* wave, float* X, int R, int64_t n, int T, hipStream_t s)
 {
-    if (fft_two_frames()) {
-        static const int slots = resident_slots((const void*)stft2_kernel<false>);
-        int sch = frames_per_workgroup(T, R, slots, 0);
-        sch += sch & 1;                                     // pairs of frames
-        hipLaunchKernelGGL(stft2_kernel<false>, dim3((unsigned)((T + sch - 1) / sch), R), dim3(256), 0, s, tb, wave, X, n, T, sch);
-        return;
-    }
     static const int slots = resident_slots((const void*)stft_kernel<false>);
     const int sch = frames_per_workgroup(T, R, slots, 0);
     dim3 grid((unsigned)((T + sch - 1) / sch), R);
