@@ -149,6 +149,7 @@ struct bsrnn_ctx {
     std::map<std::pair<int, int>, OvlTable> ovl_tables;       // per (rows C, frames T): consumer dispatch orders by readiness
     hipEvent_t ev_ovl_fork = nullptr, ev_ovl_join = nullptr;
     int ovl_epoch = 0;              // overlapped calls so far on this context (upper bits of the progress words, kernels.h); reset every 2^18
+    int ovl_epoch_period = 1 << 18; // (test hook BSRNN_OVL_EPOCHS: a short period exercises the reset)
     int ovl_resident_total[2] = {0, 0};      // time-axis workgroups the two resident counters have been promised so far (the gates' targets)
     bool ovl_unjoined = false;      // the auxiliary stream may still be draining the last overlapped call (a host-side join follows where one is needed)
     // How a consumer launch is held back until every workgroup of its producer is resident: a one-wave gate kernel that spins on the
@@ -733,7 +734,7 @@ void run_overlapped(bsrnn_ctx* c, Part p, const bsrnn_ctx::OvlTable* tb, int fir
     if (!serial) pb.s = B;
     const int nwg = (p.C * c->K + 3) / 4, limit = OVL_SPIN_LIMIT;
     // this call's epoch (upper bits of every progress word it publishes or waits for) and the gates' targets (running totals)
-    if (++c->ovl_epoch >= (1 << 18) || c->ovl_resident_total[0] > (1 << 30) || c->ovl_resident_total[1] > (1 << 30)) {   // start again: nothing in flight, every word zero
+    if (++c->ovl_epoch >= c->ovl_epoch_period || c->ovl_resident_total[0] > (1 << 30) || c->ovl_resident_total[1] > (1 << 30)) {   // start again: nothing in flight, every word zero
         (void)hipDeviceSynchronize();
         (void)hipMemset(c->d_ovl, 0, (size_t)2 * c->ovl_stride * sizeof(int));
         for (int b = 0; b < 2; ++b) if (c->ovl_sig[b]) (void)hipMemset(c->ovl_sig[b], 0, 8);
@@ -982,6 +983,7 @@ int bsrnn_create(int device, const int32_t* widths, int32_t n_bands, bsrnn_ctx**
         if (!strcmp(e, "mask")) c->overlap_mode = 2;
         if (!strcmp(e, "pub")) c->overlap_mode = 3 | 4;
     }
+    if (const char* e = getenv("BSRNN_OVL_EPOCHS")) c->ovl_epoch_period = std::max(2, std::min(1 << 18, atoi(e)));
     if (const char* e = getenv("BSRNN_PARTS")) c->n_parts = std::max(0, std::min(MAX_PARTS, atoi(e)));
     if (const char* e = getenv("BSRNN_PART_LAG")) c->part_lag = std::max(0, std::min((int)MS_COUNT, atoi(e)));
 

@@ -11,10 +11,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def make_model(sd, overlap):
+def make_model(sd, overlap, epochs=None):
     """A model whose context is created under BSRNN_OVERLAP=<overlap> (read once per context, csrc/api.hip::bsrnn_create)."""
     from speechseparation_amd.bsrnn import BSRNN
     old = os.environ.get("BSRNN_OVERLAP")
+    if epochs is not None:
+        os.environ["BSRNN_OVL_EPOCHS"] = str(epochs)
     if overlap is None:
         os.environ.pop("BSRNN_OVERLAP", None)
     else:
@@ -25,6 +27,7 @@ def make_model(sd, overlap):
         m = m.to("cuda")
         m._context(torch.device("cuda", torch.cuda.current_device()))
     finally:
+        os.environ.pop("BSRNN_OVL_EPOCHS", None)
         if old is None:
             os.environ.pop("BSRNN_OVERLAP", None)
         else:
@@ -135,3 +138,21 @@ def test_batches_in_flight_on_contexts_of_their_own_equal_one_after_the_other(sd
         with torch.cuda.stream(streams[j]):
             m.sync()                                                  # (raises on a guard word left set)
         assert m.overlap_state() == 1
+
+
+def test_progress_word_epochs_start_again(sd_hot, models):
+    """The progress words carry the call's number on the context in their upper bits and start again every 2^18 calls (device idle, words
+    zeroed).  With the period set to 5 calls (test hook BSRNN_OVL_EPOCHS) the restart happens every few calls, between calls of two shapes:
+    every result equals the serial flow."""
+    from speechseparation_amd import weights
+    _, ser = models
+    m = make_model(sd_hot, None, epochs=5)
+    m.set_range_policy("deferred")
+    shapes = [(64, 128000, 7), (20, 70 * 1024 + 100, 8)]
+    waves = [torch.from_numpy(weights.synth_waveform(r, n, seed=sd)).cuda() for r, n, sd in shapes]
+    refs = [ser.separate(w).clone() for w in waves]
+    for i in range(23):
+        k = i % 2
+        assert torch.equal(m.separate(waves[k]), refs[k]), "call %d" % i
+    m.sync()
+    assert m.overlap_state() == 1
