@@ -1552,6 +1552,471 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w_kernel(const float* __rest
 }
 
 // =====================================================================================
+// The same kernel for EIGHT sequences per workgroup (round 4, experimental: BSRNN_TIME_SEQ8=1).  Why: a time-axis launch is a latency chain that
+// holds one CU per workgroup while using a fraction of it - 192 CUs at 64 rows -, and what runs beside it in the overlapped dual path (the second
+// band block, the mask chain: api.hip::run_overlapped) is limited by the CUs left, not by its data (profiles/r04c_overlap_timeline.txt).  Half the
+// workgroups leave 160 CUs instead of 64.  What changes against time_lstm_h2w_kernel: every row of the 16-row MFMA tiles carries data - recurrent
+// form: row 2 j = first piece of sequence j, row 2 j + 1 = its second piece (still two MFMAs per block and gate); batched form (input half, fc):
+// row = (sequence r >> 1, step r & 1) - so a group is TWO steps, a lane owns the two cells (unit, sequence 2 q) and (unit, sequence 2 q + 1), the
+// step slots in LDS are [k / 8][8 sequences][8] per piece and the rings hold 8 steps (the same four groups).  Counters, roles, the order of every
+// cell's arithmetic: unchanged - h and the carried state are bit-identical to the four-sequence kernel (tools/time_lstm_v3_bench.hip).
+// =====================================================================================
+constexpr int TCH8 = 4, RING8 = 8;
+constexpr int TSTEP8 = 2 * 8 * HID + 32;      // halves per step slot: two pieces of [8][8][8] + 64 bytes of skew
+template <bool FUSE, bool TRACE = false, bool PART = false>
+__global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __restrict__ zin, float* __restrict__ hout,
+                                                             const uint4* __restrict__ wpk, const float* __restrict__ bias,
+                                                             const uint4* __restrict__ wfc, const float* __restrict__ bfc,
+                                                             const float* __restrict__ state_in, float* __restrict__ state_out,
+                                                             int R, int T, int K, int* __restrict__ range_flag, unsigned long long* __restrict__ dbg,
+                                                             const float* __restrict__ part = nullptr, int* ovl_resident = nullptr, int* ovl_prog = nullptr, int ovl_base = 0)
+{
+    unsigned long long tp[4] = {0, 0, 0, 0}, tq = 0;          // measurement only
+    auto stamp = [&](int k) { if (TRACE) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); tp[k] += now - tq; tq = now; } };
+    __shared__ __attribute__((aligned(16))) _Float16 xpl[2 * TCH8 * TSTEP8];   // [chunk slot][step in chunk]: a ring of 8 steps
+    __shared__ __attribute__((aligned(16))) _Float16 h0pl[RING8 * TSTEP8];     // h0_t in slot t & 7
+    __shared__ __attribute__((aligned(16))) _Float16 h1pl[RING8 * TSTEP8];     // h1_t in slot t & 7
+    __shared__ __attribute__((aligned(16))) float pinb[2 * 2 * 2 * 4 * 512];   // [layer][group parity][step in group][gate][cell]: bias + input half
+    __shared__ __attribute__((aligned(16))) uint4 wflds[FUSE ? 4 * 4 * 64 : 1];
+    __shared__ int sync[SY_COUNT];            // the counters (and the abort word) of lds_wait_ge / lds_arrive
+    __shared__ float hb_lds[PART ? 512 : 1];  // PART: the helpers' biases [layer][gate][unit]
+    __shared__ int outc[8];                   // overlapped dual path: storing waves that have drained group f, in slot f & 7 (monotonic: 4 per use)
+
+    const int N = R * K;
+    const int n0 = blockIdx.x * 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                 // wave-uniform: the roles below are scalar branches
+    const int role = wave >> 2, w4 = wave & 3;
+    const int layer = role & 1;
+    const int n = lane & 15, q = lane >> 4;
+    const int unit = 16 * w4 + n;
+    const int cellid = w4 * 64 + lane;
+    const size_t tstride = (size_t)K * HID;
+    const int G = (T + 1) >> 1;                  // groups of two steps
+
+    // this lane's two cells: (unit, sequence 2 q) and (unit, sequence 2 q + 1)
+    int nq_raw[2], nq[2];
+    size_t base_q[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        nq_raw[j] = n0 + 2 * q + j;
+        nq[j] = nq_raw[j] < N ? nq_raw[j] : N - 1;
+        base_q[j] = ((size_t)(nq[j] / K) * T * K + (nq[j] % K)) * HID;
+    }
+    const int cell0 = (w4 * 8 + 2 * q) * 16 + n; // index of the first cell in pinb's [cell] axis (the second: + 16)
+    const int afrag = (q * 8 + (n >> 1)) * 8;    // A fragment inside a 32-deep block of a piece: row l & 15 = (sequence (l & 15) >> 1, ...)
+    const int bstep = n & 1;                     // ... batched form: step (l & 15) & 1 of the group
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (tid < SY_COUNT) sync[tid] = 0;
+    if (tid >= 64 && tid < 72) outc[tid - 64] = 0;
+    // overlapped dual path (kernels.h, OvlProducer): this workgroup is on the chip - the launch that consumes its output is let go when all are
+    if (PART && tid == 0 && ovl_resident) __hip_atomic_fetch_add(ovl_resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (may be a signal word the command processor polls)
+    if (TRACE) tq = __builtin_amdgcn_s_memrealtime();
+
+    // The two role families are laid out as "helpers: ...; return;  main waves: ..." and not as if / else: with a join behind both, the
+    // structurizer keeps the values of the path laid out second alive through the first one's loops (a wave runs only one of them, but
+    // the compiler sees entry -> helpers -> join -> main as a path) - a dozen registers the 128-VGPR budget of 16 waves per CU does not have.
+    auto finish = [&]() {
+        if (lds_peek(&sync[SY_ABORT]) && range_flag) *range_flag = 3;
+        if (TRACE && lane == 0 && blockIdx.x < 4) {
+            unsigned long long* d = dbg + (blockIdx.x * 16 + wave) * 4;
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = tp[k];
+        }
+    };
+    if (role >= 2) {
+        // ------------------------------------------------------------------ helper waves: input halves, x staging, fc
+        h8v w[2][4][2];                           // W_ih (fc_in folded for layer 0): [k block][gate][piece]
+        {
+            const uint4* wp = wpk + ((size_t)(layer * 4 + w4) * 4 * 4 * 2) * 64 + lane;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[((b * 4 + gte) * 2 + pc) * 64]);
+        }
+        float bs[4];
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) {
+            bs[gte] = bias[layer * 256 + gte * 64 + unit];
+            if (PART) hb_lds[layer * 256 + gte * 64 + unit] = bs[gte];      // (read back after the workgroup's first barrier)
+        }
+        float bf = 0.f;
+        if (FUSE && layer) {                      // the fc matrix as B fragments [k block][piece] (column = output feature `unit`): used once per
+            const uint4* wp = wfc + ((size_t)w4 * 2 * 2) * 64 + lane;       // group, so it lives in LDS; a wave reads back what it wrote itself
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wflds[(w4 * 4 + i) * 64 + lane] = wp[i * 64];
+            bf = bfc[unit];
+        }
+        // input half of the four steps of `group` (A rows = (sequence, step), `src` = slot of the group's first step): per gate
+        // 6 MFMAs, then bias + result to the LDS buffer the main wave of this cell reads, [step][gate][cell]
+        auto input_half = [&](const _Float16* src, int group) {
+            if (TIME_ABL & 8) return;
+            const _Float16* mine = src + bstep * TSTEP8;
+            h8v a0[2], a1[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                a0[b] = *reinterpret_cast<const h8v*>(&mine[b * 256 + afrag]);
+                a1[b] = *reinterpret_cast<const h8v*>(&mine[8 * HID + b * 256 + afrag]);
+            }
+            float* dst = pinb + layer * 8192 + (group & 1) * 4096 + cell0;
+            float bsg[4];                         // PART: the biases come from LDS per group instead of living in four registers across the
+#pragma unroll                                    // loop - the kernel has none to spare (no scratch: see H0)
+            for (int gte = 0; gte < 4; ++gte) bsg[gte] = PART ? hb_lds[layer * 256 + gte * 64 + unit] : bs[gte];
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) {
+                v4f ghi = zero4, glo = zero4;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (TIME_ABL & 2) { ghi[0] += (float)a0[b][0] * (float)w[b][gte][0][0]; glo[1] += (float)a1[b][1] * (float)w[b][gte][1][1]; continue; }
+                    ghi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][0], ghi, 0, 0, 0);
+                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][1], glo, 0, 0, 0);
+                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[b], w[b][gte][0], glo, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)       // row 4 q + e of the tile = (sequence 2 q + (e >> 1), step e & 1)
+                    dst[(e & 1) * 2048 + gte * 512 + (e >> 1) * 16] = bsg[gte] + (ghi[e] + glo[e] * (1.f / 2048.f));
+            }
+        };
+        if (!layer) {
+            // ---------------- H0: x staging (its 256 threads: 8 steps x 4 sequences x 16 float4 = 512 float4, two per thread) and
+            // the input half of layer 0.  Chunk c (steps 8 c ...) lives in slot c & 1; it is requested a whole chunk ahead,
+            // stored once every H0 wave has published the groups that read the slot's previous content, and read once every
+            // H0 wave has stored its share.
+            const int xs_t = cellid >> 7, xs_i = (cellid >> 4) & 7, xs_c4 = cellid & 15;      // thread -> (step 0-1 [+2], sequence, float4)
+            size_t xs_base;
+            {
+                int ni = n0 + xs_i; ni = ni < N ? ni : N - 1;
+                xs_base = ((size_t)(ni / K) * T * K + (ni % K)) * HID + 4 * xs_c4;
+            }
+            float amax = 0.f;                    // range guard
+            struct XRows { float4 z[2]; };
+            auto chunk_load = [&](int chunk, XRows& v) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    int t = chunk * TCH8 + xs_t + 2 * hf;
+                    t = t < T ? t : T - 1;
+                    v.z[hf] = *reinterpret_cast<const float4*>(zin + xs_base + (size_t)t * tstride);
+                }
+            };
+            auto chunk_store = [&](int chunk, const XRows& v) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float f[4] = {v.z[hf].x, v.z[hf].y, v.z[hf].z, v.z[hf].w};
+                    h4v p0, p1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
+                        _Float16 a, b2;
+                        split_h2(f[e], a, b2);
+                        p0[e] = a; p1[e] = b2;
+                    }
+                    _Float16* dst = &xpl[((chunk & 1) * TCH8 + xs_t + 2 * hf) * TSTEP8 + ((xs_c4 >> 1) * 8 + xs_i) * 8 + (xs_c4 & 1) * 4];
+                    *reinterpret_cast<h4v*>(dst) = p0;
+                    *reinterpret_cast<h4v*>(dst + 8 * HID) = p1;
+                }
+            };
+            auto xslot = [&](int t) { return &xpl[(t & (2 * TCH8 - 1)) * TSTEP8]; };
+            if (PART) {
+                // PART stages group by group instead of chunk by chunk: three rows per (sequence, step) - residual and the two fc shares -
+                // would be 24 registers held across the input half (the kernel then spills: 1024 threads leave 128 VGPRs per wave);
+                // one group's rows are 12.  A group's four steps are requested one group ahead, stored (summed) at the top of the
+                // next iteration once every wave has published the group that used the same slots (four groups = 16 steps earlier).
+                struct GRows { float4 z, pf, pb; };
+                auto rows_of = [&](int g) { int t = 2 * g + xs_t; t = t < T ? t : T - 1; return xs_base + (size_t)t * tstride; };
+                auto load_z = [&](int g, GRows& v) { v.z = *reinterpret_cast<const float4*>(zin + rows_of(g)); };
+                auto load_shares = [&](int g, GRows& v) {
+                    const float* pp = part + 2 * (rows_of(g) - 4 * xs_c4) + 4 * xs_c4;
+                    v.pf = *reinterpret_cast<const float4*>(pp);
+                    v.pb = *reinterpret_cast<const float4*>(pp + HID);
+                };
+                auto group_store = [&](int g, const GRows& v) {
+                    const float f[4] = {(v.z.x + v.pf.x) + v.pb.x, (v.z.y + v.pf.y) + v.pb.y, (v.z.z + v.pf.z) + v.pb.z, (v.z.w + v.pf.w) + v.pb.w};
+                    h4v p0, p1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
+                        _Float16 a, b2;
+                        split_h2(f[e], a, b2);
+                        p0[e] = a; p1[e] = b2;
+                    }
+                    _Float16* dst = xslot(2 * g + xs_t) + ((xs_c4 >> 1) * 8 + xs_i) * 8 + (xs_c4 & 1) * 4;
+                    *reinterpret_cast<h4v*>(dst) = p0;
+                    *reinterpret_cast<h4v*>(dst + 8 * HID) = p1;
+                    // ... and to the OUTPUT buffer, where the fc wave (H1) picks it up as its residual two groups later and then
+                    // overwrites it with the block's result: one read of the three rows instead of two.  Same workgroup, same CU:
+                    // the store is complete (vmcnt(0) in front of this wave's PIN0 arrival below) long before the chain H0 -> M0 ->
+                    // H1 of LDS counters lets H1 ask for it, and nobody has read that line before (no stale copy in the L1).
+                    if (n0 + xs_i < N && 2 * g + xs_t < T) {
+                        if (OVL_DBG & 4) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) __hip_atomic_store((float __attribute__((address_space(1)))*)(hout + rows_of(g) + e), f[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else
+                        *reinterpret_cast<float4*>(hout + rows_of(g)) = make_float4(f[0], f[1], f[2], f[3]);
+                    }
+                };
+                // Only the residual row (4 registers) is in flight across an input half; the two share rows of the next group are
+                // requested BEHIND it and land during the waits at the top of the next iteration: the kernel must stay inside 128
+                // VGPRs without scratch (with spills - the weight fragments, reloaded in the loops - a call beside a second
+                // process's first kernels came out a few ulp different once in ~50: tools/busy_start_stress.py).
+                GRows xr;
+                load_z(0, xr); load_shares(0, xr); group_store(0, xr);
+                if (G > 1) { load_z(1, xr); load_shares(1, xr); }
+                __syncthreads();
+                for (int g = 0; g < G; ++g) {
+                    if (g) {
+                        if (g >= 4) lds_wait_ge(sync, SY_PIN0, 4 * (g - 3));   // group g - 4 (the same slots) is published by every wave
+                        group_store(g, xr);
+                        lds_arrive(&sync[SY_X], lane);
+                        if (g + 1 < G) load_z(g + 1, xr);
+                        lds_wait_ge(sync, SY_X, 4 * g);                    // every wave has stored its share of group g
+                    }
+                    if (g >= 2) lds_wait_ge(sync, SY_DONE0, 8 * (g - 1));    // layer 0 has finished group g - 2 (same buffer)
+                    stamp(0);
+                    input_half(xslot(2 * g), g);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's row stores of the group are in L2
+                    lds_arrive(&sync[SY_PIN0], lane);
+                    if (g && g + 1 < G) load_shares(g + 1, xr);
+                    stamp(2);
+                }
+            } else {
+            XRows xnext;
+            chunk_load(0, xnext); chunk_store(0, xnext);
+            if (TCH8 < T) chunk_load(1, xnext);
+            __syncthreads();
+            for (int g = 0; g < G; ++g) {
+                const int ch = g >> 1;
+                if (g && !(g & 1)) {                                  // first group of chunk ch >= 1
+                    lds_wait_ge(sync, SY_PIN0, 4 * (2 * ch - 2));    // the groups that read chunk ch - 2 (same slot) are published by every wave
+                    chunk_store(ch, xnext);
+                    lds_arrive(&sync[SY_X], lane);
+                    if ((ch + 1) * TCH8 < T) chunk_load(ch + 1, xnext);
+                    lds_wait_ge(sync, SY_X, 4 * ch);                 // every wave has stored its share of chunk ch
+                }
+                if (g >= 2) lds_wait_ge(sync, SY_DONE0, 8 * (g - 1));    // layer 0 has finished group g - 2 (same buffer)
+                stamp(0);
+                input_half(xslot(2 * g), g);
+                if (g) lds_wait_ge(sync, SY_PIN0, 4 * g);             // (SY_PIN0 is a sum over the four waves: no wave two groups ahead of another, see H1)
+                lds_arrive(&sync[SY_PIN0], lane);
+                stamp(2);
+            }
+            }
+            if (!(amax <= 65504.f) && range_flag) *range_flag = 1;
+        } else {
+            // ---------------- H1: input half of layer 1 (A = h0 of the group, complete once layer 0 has finished its last step)
+            // FUSE: fc + residual of a group of layer 1 in two stages, so that H1 never waits for anything but its own gates: the
+            // residual rows of group f are REQUESTED in iteration f + 1 (fc_request) and the group is finished in iteration f + 2
+            // (fc_finish: A rows = (sequence, step) of h1 as in the batched input half, 6 MFMAs, epilogue), when the gate that
+            // iteration waits for anyway - layer 1 has finished group f - says its h1 is complete
+            float xres[4] = {0.f, 0.f, 0.f, 0.f};  // [e]: (sequence 2 q + (e >> 1), step e & 1) of the group, as the tile's rows
+            const float* const res_src = PART ? hout : zin;     // PART: the staging wave left the summed row (residual + fc shares) in the output buffer
+            auto fc_request = [&](int f) {
+                const int ffirst = 2 * f, nst = T - ffirst < 2 ? T - ffirst : 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const size_t row = base_q[e >> 1] + (size_t)(ffirst + ((e & 1) < nst ? (e & 1) : nst - 1)) * tstride;
+                    xres[e] = res_src[row + unit];
+                }
+            };
+            // Overlapped dual path: the output rows of group f are in memory (every store of them write-through, this wave's drained by the
+            // vmcnt(0) here; the last of the four storing waves to say so for f tells the consumers - each wave works through the groups in
+            // order and drains all its older stores with it, so f + 1 published groups mean groups 0 .. f are complete whichever wave
+            // published them).  Called one group late, where the wave waits for its residual loads anyway: no extra stall on H1.
+            const bool pub = FUSE && PART && ovl_prog != nullptr;       // (only the parts flow overlaps: api.hip)
+            // The consumers work in tiles of 16 frames and more, so progress is published every FOURTH group (and at the end): one drain per 16
+            // steps instead of one per 4 keeps H1's stalls on its write-through stores off the chain (each drain covers all the wave's older stores).
+            auto publish = [&](int f) {
+                if ((f & 7) != 7 && f != G - 1) return;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(&outc[(f >> 3) & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = __builtin_amdgcn_readfirstlane(old);
+                // (absolute value, epoch in the upper bits, atomic MAX: the four-group publishes of a workgroup may come from different waves out of order)
+                // (the consumers count in groups of FOUR frames, kernels.h::ovl_wait_rows: frames done = min(2 (f + 1), T))
+                const int done4 = f == G - 1 ? (T + 3) >> 2 : (f + 1) >> 1;
+                if ((old & 3) == 3 && lane == 0) __hip_atomic_fetch_max(ovl_prog + blockIdx.x, ovl_base + done4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            auto fc_finish = [&](int f) {
+                if (pub && f >= 1) publish(f - 1);
+                const int ffirst = 2 * f, nst = T - ffirst < 2 ? T - ffirst : 2;
+                const _Float16* mine = &h1pl[((ffirst & (RING8 - 1)) + bstep) * TSTEP8];
+                v4f fhi = zero4, flo = zero4;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const h8v f0 = *reinterpret_cast<const h8v*>(&mine[b * 256 + afrag]);
+                    const h8v f1 = *reinterpret_cast<const h8v*>(&mine[8 * HID + b * 256 + afrag]);
+                    const h8v wf0 = __builtin_bit_cast(h8v, wflds[(w4 * 4 + b * 2 + 0) * 64 + lane]);
+                    const h8v wf1 = __builtin_bit_cast(h8v, wflds[(w4 * 4 + b * 2 + 1) * 64 + lane]);
+                    fhi = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf0, fhi, 0, 0, 0);
+                    flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, wf1, flo, 0, 0, 0);
+                    flo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, wf0, flo, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);                // one block's fragments at a time (registers)
+                }
+                lds_arrive(&sync[SY_FC], lane);                       // the group's h1 slots are free again
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((e & 1) < nst && nq_raw[e >> 1] < N) {
+                        const float v = ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + xres[e];
+                        float* const dst = hout + base_q[e >> 1] + (size_t)(ffirst + (e & 1)) * tstride + unit;
+                        if (pub) __hip_atomic_store((float __attribute__((address_space(1)))*)dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dword sc1
+                        else *dst = v;
+                    }
+            };
+            __syncthreads();
+            for (int g = 0; g < G; ++g) {
+                const int last = 2 * g + 2 < T ? 2 * g + 2 : T;
+                lds_wait_ge(sync, SY_DONE0, 4 * last);               // h0 of the group complete
+                if (g >= 2) lds_wait_ge(sync, SY_DONE1, 8 * (g - 1));    // layer 1 has finished group g - 2 (same buffer; its h1 is complete)
+                stamp(0);
+                input_half(&h0pl[((2 * g) & (RING8 - 1)) * TSTEP8], g);
+                // SY_PIN1 and SY_FC are SUMS over the four H1 waves, and their waiters (M1: this group's input half is published; M0 / M1:
+                // a ring slot has been read) conclude "every wave has done group g" from "sum >= 4 (g + 1)".  That only holds while no wave
+                // is two groups ahead of another - and nothing else ties the H1 waves to each other: one of them stalled for a few
+                // microseconds on global memory (its residual loads, its output stores) while the other three went on gave M1 a group
+                // whose input half - or an h1 slot whose fc read - was the stalled wave's old one: 16 units of four sequences slightly
+                // wrong from a group boundary on.  Seen once in ~100 calls with write-through output stores (overlapped dual path,
+                // tools/overlap_probe.py), and the likely cause of round 3's "result depended on a second process starting" (DESIGN 4e).
+                // So a wave publishes group g only when all four have published g - 1: skew <= 1 group, for which the sums are exact.
+                if (g) lds_wait_ge(sync, SY_PIN1, 4 * g);
+                lds_arrive(&sync[SY_PIN1], lane);
+                stamp(2);
+                if (FUSE) {
+                    if (g >= 2) fc_finish(g - 2);
+                    if (g >= 1) fc_request(g - 1);
+                }
+                stamp(1);
+            }
+            if (FUSE) {                           // the last two groups
+                if (G >= 2) { lds_wait_ge(sync, SY_DONE1, 8 * (G - 1)); fc_finish(G - 2); }
+                fc_request(G - 1);
+                lds_wait_ge(sync, SY_DONE1, 4 * T);
+                fc_finish(G - 1);
+                if (pub) publish(G - 1);
+            }
+        }
+        finish();
+        return;
+    }
+    {
+        // ------------------------------------------------------------------ main waves: the serial chain
+        h8v w[2][4][2];                           // W_hh: [k block][gate][piece]
+        {
+            const uint4* wp = wpk + ((size_t)(layer * 4 + w4) * 4 * 4 * 2) * 64 + lane;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[(((2 + b) * 4 + gte) * 2 + pc) * 64]);
+        }
+        const int hoff = ((unit >> 3) * 8 + 2 * q) * 8 + (unit & 7);  // where this lane's first cell's h goes inside a piece (the second: + 8)
+        _Float16* const ring = layer ? h1pl : h0pl;
+        const int rmask = RING8 - 1;
+        float c[2], hsel[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            c[j] = state_in ? state_in[((size_t)(2 + layer) * N + nq[j]) * HID + unit] : 0.f;
+            const float hinit = state_in ? state_in[((size_t)layer * N + nq[j]) * HID + unit] : 0.f;
+            _Float16 p0, p1;
+            split_h2(hinit, p0, p1);
+            _Float16* hb = &ring[rmask * TSTEP8];                     // h_{-1}
+            hb[hoff + 8 * j] = p0;
+            hb[8 * HID + hoff + 8 * j] = p1;
+        }
+        // Only rows 4j of the 16-row tile carry a sequence, so row 4j + 1 is given the SECOND piece of the same sequence: one
+        // MFMA against w1 yields a1 w1 in register 0 and a2 w1 in register 1 of the owning lane, a second one against w2
+        // yields a1 w2 in register 0 - two MFMAs per (block, gate) instead of three, one fragment read per block.
+        const int rfrag = afrag + ((n & 1) ? 8 * HID : 0);            // (every row of the tile carries a sequence's piece: 2 j = first, 2 j + 1 = second)
+        const float* const pin_l = pinb + layer * 8192 + cell0;
+        const int my_done = layer ? SY_DONE1 : SY_DONE0, my_pin = layer ? SY_PIN1 : SY_PIN0;
+        // whoever reads this layer's ring besides the layer itself: H1 batches h0 and (fc) h1
+        const int reader = layer ? SY_FC : SY_PIN1;
+        const bool has_reader = layer ? FUSE : true;
+        const int rsteps = RING8;
+        __syncthreads();                          // h_{-1}, counters, x chunk 0 (the helpers publish group 0 behind it)
+        if (TIME_OPT & 1) __builtin_amdgcn_s_setprio(2);     // the chain before the helpers wherever both could issue
+        for (int t = 0; t < T; ++t) {
+            if ((t & 1) == 0) {
+                if (!(TIME_ABL & 1)) lds_wait_ge(sync, my_pin, 4 * ((t >> 1) + 1));              // this group's input half is published
+                if (has_reader && t >= rsteps) lds_wait_ge(sync, reader, 4 * (((t - rsteps) >> 1) + 1));   // the slots this group overwrites have been read
+            }
+            stamp(3);
+            const _Float16* src = &ring[((t - 1) & rmask) * TSTEP8];
+            h8v a[2];
+            if (TIME_OPT & 2) {
+                // h_{t-1} complete (all four waves)?  The counter and the two fragments are requested together - LDS operations of a
+                // wave execute in order, so fragments that follow a counter value >= 4 t are complete - and requested again if not:
+                // one LDS round trip per step instead of two.
+                const unsigned ca = (unsigned)(size_t)&sync[my_done], fa = (unsigned)(size_t)&src[rfrag];
+                int spins = 0;
+                for (;;) {
+                    int cv;
+                    u4v f0, f1;
+                    asm volatile("ds_read_b32 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(cv), "=&v"(f0), "=&v"(f1) : "v"(ca), "v"(fa) : "memory");
+                    a[0] = __builtin_bit_cast(h8v, f0); a[1] = __builtin_bit_cast(h8v, f1);
+                    if ((TIME_ABL & 4) || __builtin_amdgcn_readfirstlane(cv) >= 4 * t) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT) __hip_atomic_store(&sync[SY_ABORT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (spins > 64 && lds_peek(&sync[SY_ABORT])) break;
+                }
+            } else {
+                if (!(TIME_ABL & 4)) lds_wait_ge(sync, my_done, 4 * t);                          // h_{t-1} complete (all four waves)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) a[b] = *reinterpret_cast<const h8v*>(&src[b * 256 + rfrag]);
+            }
+            stamp(2);
+            const float* const pin_t = pin_l + (((t >> 1) & 1) * 2 + (t & 1)) * 2048;
+            float pin_i[2], pin_f[2], pin_g[2], pin_o[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { pin_i[j] = pin_t[16 * j]; pin_f[j] = pin_t[512 + 16 * j]; pin_g[j] = pin_t[1024 + 16 * j]; pin_o[j] = pin_t[1536 + 16 * j]; }
+            v4f hi[4], lo[4];
+#pragma unroll
+            for (int gte = 0; gte < 4; ++gte) { hi[gte] = zero4; lo[gte] = zero4; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte) hi[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[b], w[b][gte][0], hi[gte], 0, 0, 0);
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte) lo[gte] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[b], w[b][gte][1], lo[gte], 0, 0, 0);
+            }
+            // hi[g] = {a1 w1, a2 w1 | the same of the second cell}, lo[g] = {a1 w2, - | a1 w2, -} of this lane's two cells
+            _Float16* hb = &ring[(t & rmask) * TSTEP8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float ig = fast_sigmoid(pin_i[j] + (hi[0][2 * j] + (hi[0][2 * j + 1] + lo[0][2 * j]) * (1.f / 2048.f)));
+                const float fg = fast_sigmoid(pin_f[j] + (hi[1][2 * j] + (hi[1][2 * j + 1] + lo[1][2 * j]) * (1.f / 2048.f)));
+                const float gg = fast_tanh(pin_g[j] + (hi[2][2 * j] + (hi[2][2 * j + 1] + lo[2][2 * j]) * (1.f / 2048.f)));
+                const float og = fast_sigmoid(pin_o[j] + (hi[3][2 * j] + (hi[3][2 * j + 1] + lo[3][2 * j]) * (1.f / 2048.f)));
+                c[j] = fg * c[j] + ig * gg;
+                hsel[j] = og * fast_tanh(c[j]);
+                _Float16 p0, p1;
+                split_h2(hsel[j], p0, p1);
+                hb[hoff + 8 * j] = p0;
+                hb[8 * HID + hoff + 8 * j] = p1;
+            }
+            lds_arrive(&sync[my_done], lane);
+            if (!FUSE && layer) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (nq_raw[j] < N) hout[base_q[j] + (size_t)t * tstride + unit] = hsel[j];
+            }
+            stamp(0);
+        }
+        if (state_out) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (nq_raw[j] < N) {
+                    state_out[((size_t)layer * N + nq[j]) * HID + unit] = hsel[j];           // h_{T-1}
+                    state_out[((size_t)(2 + layer) * N + nq[j]) * HID + unit] = c[j];        // c_{T-1}
+                }
+        }
+    }
+    finish();
+}
+
+// =====================================================================================
 // Band-axis block for a HANDFUL of sequences (the one-frame streaming step: N = C frame rows = 2 sequences of K = 12 bands):
 // BandwiseLSTM's whole NormRNNResidual (bsrnn.py:138-153, :78-87) - layer 0 in both directions, layer 1 in both directions,
 // fc(128 -> 64) + bias + residual - in ONE workgroup per four sequences, instead of two band_lstm_h2 launches (two 4-wave

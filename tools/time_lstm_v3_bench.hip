@@ -91,6 +91,33 @@ static int run(int R, int T, int K, bool with_state, int reps)
     size_t untouched = 0;
     for (size_t i = 0; i < nz; ++i) { uint32_t u; memcpy(&u, &f[i], 4); untouched += u == 0xffffffffu; }
     printf("   fused output words never written: %zu\n", untouched);
+    size_t nd8 = 0, ndf8 = 0, nds8 = 0, ndsf8 = 0;
+    {   // the eight-sequence kernel (time_lstm_h2w8_kernel): h1 / the fused output / the carried state bit for bit against the four-sequence kernel's
+        float *h8p, *h8f, *so8, *so8f;
+        CK(hipMalloc(&h8p, nz * 4)); CK(hipMalloc(&h8f, nz * 4)); CK(hipMalloc(&so8, nst * 4)); CK(hipMalloc(&so8f, nst * 4));
+        CK(hipMemset(h8p, 0xff, nz * 4)); CK(hipMemset(h8f, 0xff, nz * 4));
+        const dim3 grid8((N + 7) / 8);
+        float best8[2] = {1e9f, 1e9f};
+        for (int rep = 0; rep < reps; ++rep)
+            for (int v = 0; v < 2; ++v) {
+                CK(hipEventRecord(e0, 0));
+                if (v == 0) hipLaunchKernelGGL((time_lstm_h2w8_kernel<false, false>), grid8, block16, 0, 0, z, h8p, (const uint4*)w, b, (const uint4*)nullptr, (const float*)nullptr, sin_, so8, R, T, K, (int*)nullptr, dbg);
+                else hipLaunchKernelGGL((time_lstm_h2w8_kernel<true, false>), grid8, block16, 0, 0, z, h8f, (const uint4*)w, b, (const uint4*)wfc, bfc, sin_, so8f, R, T, K, (int*)nullptr, dbg);
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) best8[v] = std::min(best8[v], ms * 1e3f);
+            }
+        CK(hipGetLastError());
+        std::vector<uint32_t> u8(nz), uf8(nz), us8(nst), usf8(nst), uf4(nz);
+        CK(hipMemcpy(u8.data(), h8p, nz * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(uf8.data(), h8f, nz * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(us8.data(), so8, nst * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(usf8.data(), so8f, nst * 4, hipMemcpyDeviceToHost));
+        memcpy(uf4.data(), f.data(), nz * 4);
+        for (size_t i = 0; i < nz; ++i) { nd8 += u8[i] != c[i]; ndf8 += uf8[i] != uf4[i]; }
+        for (size_t i = 0; i < nst; ++i) { nds8 += us8[i] != sb[i]; ndsf8 += usf8[i] != sc[i]; }
+        printf("   EIGHT sequences per workgroup (%d workgroups): %.1f us | + fused fc %.1f us;  words that differ from the four-sequence kernel: h1 %zu, fused output %zu, state %zu / %zu\n",
+               (N + 7) / 8, best8[0], best8[1], nd8, ndf8, nds8, ndsf8);
+        hipFree(h8p); hipFree(h8f); hipFree(so8); hipFree(so8f);
+    }
     if (reps > 2)            // phase stamps of the 16-wave kernel, without and with the fused fc
         for (int fz = 0; fz < 2; ++fz) {
             if (fz) hipLaunchKernelGGL((time_lstm_h2w_kernel<true, true>), grid, block16, 0, 0, z, h_fus, (const uint4*)w, b, (const uint4*)wfc, bfc, sin_, so_fus, R, T, K, (int*)nullptr, dbg);
@@ -108,7 +135,7 @@ static int run(int R, int T, int K, bool with_state, int reps)
             printf("     wave  8 (helper 0): per group: staging + waits %.0f ns, input half %.0f ns\n", hd[8 * 4] * 10.0 / G, hd[8 * 4 + 2] * 10.0 / G);
             printf("     wave 12 (helper 1): per group: waits %.0f ns, input half %.0f ns, fc %.0f ns\n", hd[12 * 4] * 10.0 / G, hd[12 * 4 + 2] * 10.0 / G, hd[12 * 4 + 1] * 10.0 / G);
         }
-    const int fail = (nd != 0) + (nds != 0) + (ndf != 0) + (bad != 0) + (untouched != 0);
+    const int fail = (nd != 0) + (nds != 0) + (ndf != 0) + (bad != 0) + (untouched != 0) + (nd8 != 0) + (ndf8 != 0) + (nds8 != 0) + (ndsf8 != 0);
     hipFree(z); hipFree(h_old); hipFree(h_new); hipFree(h_fus); hipFree(w); hipFree(wfc); hipFree(b); hipFree(bfc);
     hipFree(st_in); hipFree(so_old); hipFree(so_new); hipFree(so_fus); hipFree(dbg);
     return fail;
