@@ -1579,7 +1579,8 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) float pinb[2 * 2 * 2 * 4 * 512];   // [layer][group parity][step in group][gate][cell]: bias + input half
     __shared__ __attribute__((aligned(16))) uint4 wflds[FUSE ? 4 * 4 * 64 : 1];
     __shared__ int sync[SY_COUNT];            // the counters (and the abort word) of lds_wait_ge / lds_arrive
-    __shared__ float hb_lds[PART ? 512 : 1];  // PART: the helpers' biases [layer][gate][unit]
+    __shared__ float hb_lds[512];            // PART: the helpers' biases [layer][gate][unit]
+    __shared__ __attribute__((aligned(16))) uint4 wsp[8 * 64];      // one W_ih fragment of every helper wave (the two cells' index math took its registers)
     __shared__ int outc[8];                   // overlapped dual path: storing waves that have drained group f, in slot f & 7 (monotonic: 4 per use)
 
     const int N = R * K;
@@ -1595,14 +1596,10 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __res
     const int G = (T + 1) >> 1;                  // groups of two steps
 
     // this lane's two cells: (unit, sequence 2 q) and (unit, sequence 2 q + 1)
-    int nq_raw[2], nq[2];
-    size_t base_q[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        nq_raw[j] = n0 + 2 * q + j;
-        nq[j] = nq_raw[j] < N ? nq_raw[j] : N - 1;
-        base_q[j] = ((size_t)(nq[j] / K) * T * K + (nq[j] % K)) * HID;
-    }
+    // (computed where they are used, not kept: the kernel has no register to spare)
+    auto nq_raw_of = [&](int j) { return n0 + 2 * q + j; };
+    auto nq_of = [&](int j) { const int v = n0 + 2 * q + j; return v < N ? v : N - 1; };
+    auto base_of = [&](int j) { const int v = nq_of(j); return ((size_t)(v / K) * T * K + (v % K)) * HID; };
     const int cell0 = (w4 * 8 + 2 * q) * 16 + n; // index of the first cell in pinb's [cell] axis (the second: + 16)
     const int afrag = (q * 8 + (n >> 1)) * 8;    // A fragment inside a 32-deep block of a piece: row l & 15 = (sequence (l & 15) >> 1, ...)
     const int bstep = n & 1;                     // ... batched form: step (l & 15) & 1 of the group
@@ -1634,14 +1631,14 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __res
 #pragma unroll
                 for (int gte = 0; gte < 4; ++gte)
 #pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) w[b][gte][pc] = __builtin_bit_cast(h8v, wp[((b * 4 + gte) * 2 + pc) * 64]);
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const uint4 v = wp[((b * 4 + gte) * 2 + pc) * 64];
+                        if (b == 0 && gte == 0 && pc == 1) wsp[((role - 2) * 4 + w4) * 64 + lane] = v;      // (read back by the same lane)
+                        else w[b][gte][pc] = __builtin_bit_cast(h8v, v);
+                    }
         }
-        float bs[4];
 #pragma unroll
-        for (int gte = 0; gte < 4; ++gte) {
-            bs[gte] = bias[layer * 256 + gte * 64 + unit];
-            if (PART) hb_lds[layer * 256 + gte * 64 + unit] = bs[gte];      // (read back after the workgroup's first barrier)
-        }
+        for (int gte = 0; gte < 4; ++gte) hb_lds[layer * 256 + gte * 64 + unit] = bias[layer * 256 + gte * 64 + unit];      // (read back after the workgroup's first barrier)
         float bf = 0.f;
         if (FUSE && layer) {                      // the fc matrix as B fragments [k block][piece] (column = output feature `unit`): used once per
             const uint4* wp = wfc + ((size_t)w4 * 2 * 2) * 64 + lane;       // group, so it lives in LDS; a wave reads back what it wrote itself
@@ -1663,15 +1660,15 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __res
             float* dst = pinb + layer * 8192 + (group & 1) * 4096 + cell0;
             float bsg[4];                         // PART: the biases come from LDS per group instead of living in four registers across the
 #pragma unroll                                    // loop - the kernel has none to spare (no scratch: see H0)
-            for (int gte = 0; gte < 4; ++gte) bsg[gte] = PART ? hb_lds[layer * 256 + gte * 64 + unit] : bs[gte];
+            for (int gte = 0; gte < 4; ++gte) bsg[gte] = hb_lds[layer * 256 + gte * 64 + unit];
 #pragma unroll
             for (int gte = 0; gte < 4; ++gte) {
                 v4f ghi = zero4, glo = zero4;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    if (TIME_ABL & 2) { ghi[0] += (float)a0[b][0] * (float)w[b][gte][0][0]; glo[1] += (float)a1[b][1] * (float)w[b][gte][1][1]; continue; }
+                    if (TIME_ABL & 2) { ghi[0] += (float)a0[b][0] * (float)w[b][gte][0][0]; continue; }
                     ghi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][0], ghi, 0, 0, 0);
-                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], w[b][gte][1], glo, 0, 0, 0);
+                    glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[b], (b == 0 && gte == 0) ? __builtin_bit_cast(h8v, wsp[((role - 2) * 4 + w4) * 64 + lane]) : w[b][gte][1], glo, 0, 0, 0);
                     glo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[b], w[b][gte][0], glo, 0, 0, 0);
                 }
 #pragma unroll
@@ -1815,7 +1812,7 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __res
                 const int ffirst = 2 * f, nst = T - ffirst < 2 ? T - ffirst : 2;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const size_t row = base_q[e >> 1] + (size_t)(ffirst + ((e & 1) < nst ? (e & 1) : nst - 1)) * tstride;
+                    const size_t row = base_of(e >> 1) + (size_t)(ffirst + ((e & 1) < nst ? (e & 1) : nst - 1)) * tstride;
                     xres[e] = res_src[row + unit];
                 }
             };
@@ -1856,9 +1853,9 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __res
                 lds_arrive(&sync[SY_FC], lane);                       // the group's h1 slots are free again
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if ((e & 1) < nst && nq_raw[e >> 1] < N) {
+                    if ((e & 1) < nst && nq_raw_of(e >> 1) < N) {
                         const float v = ((fhi[e] + flo[e] * (1.f / 2048.f)) + bf) + xres[e];
-                        float* const dst = hout + base_q[e >> 1] + (size_t)(ffirst + (e & 1)) * tstride + unit;
+                        float* const dst = hout + base_of(e >> 1) + (size_t)(ffirst + (e & 1)) * tstride + unit;
                         if (pub) __hip_atomic_store((float __attribute__((address_space(1)))*)dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dword sc1
                         else *dst = v;
                     }
@@ -1916,8 +1913,8 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __res
         float c[2], hsel[2] = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            c[j] = state_in ? state_in[((size_t)(2 + layer) * N + nq[j]) * HID + unit] : 0.f;
-            const float hinit = state_in ? state_in[((size_t)layer * N + nq[j]) * HID + unit] : 0.f;
+            c[j] = state_in ? state_in[((size_t)(2 + layer) * N + nq_of(j)) * HID + unit] : 0.f;
+            const float hinit = state_in ? state_in[((size_t)layer * N + nq_of(j)) * HID + unit] : 0.f;
             _Float16 p0, p1;
             split_h2(hinit, p0, p1);
             _Float16* hb = &ring[rmask * TSTEP8];                     // h_{-1}
@@ -2000,17 +1997,22 @@ __global__ __launch_bounds__(1024) void time_lstm_h2w8_kernel(const float* __res
             if (!FUSE && layer) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if (nq_raw[j] < N) hout[base_q[j] + (size_t)t * tstride + unit] = hsel[j];
+                    if (nq_raw_of(j) < N) hout[base_of(j) + (size_t)t * tstride + unit] = hsel[j];
             }
             stamp(0);
         }
         if (state_out) {
+            // (the lane's coordinates again, from the lane counter: nothing of the prologue's index math stays live across the step loop)
+            const int le = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int ue = 16 * w4 + (le & 15);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (nq_raw[j] < N) {
-                    state_out[((size_t)layer * N + nq[j]) * HID + unit] = hsel[j];           // h_{T-1}
-                    state_out[((size_t)(2 + layer) * N + nq[j]) * HID + unit] = c[j];        // c_{T-1}
+            for (int j = 0; j < 2; ++j) {
+                const int ne = n0 + 2 * (le >> 4) + j;
+                if (ne < N) {
+                    state_out[((size_t)layer * N + ne) * HID + ue] = hsel[j];           // h_{T-1}
+                    state_out[((size_t)(2 + layer) * N + ne) * HID + ue] = c[j];        // c_{T-1}
                 }
+            }
         }
     }
     finish();
@@ -2238,6 +2240,20 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const voi
     }
     dim3 grid((N + 3) / 4), block(512), block16(1024);
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
+        // Eight sequences per workgroup where four would need more than one round of workgroups (one per CU): the 41-band table, large batches.
+        // BSRNN_TIME_SEQ8 = 0 never / 1 always (A/B, tests); results are bit-identical either way.
+        static const int seq8 = [] { const char* e = getenv("BSRNN_TIME_SEQ8"); return e ? atoi(e) : -1; }();
+        static const int cus = [] { int d = 0, n = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0 ? n : 256; }();
+        if (time_lstm_fuses_fc() && fc16 && fcb && !ovl && (seq8 == 1 || (seq8 < 0 && (N + 3) / 4 > cus))) {
+            const dim3 grid8((N + 7) / 8);
+            if (part)
+                hipLaunchKernelGGL((time_lstm_h2w8_kernel<true, false, true>), grid8, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
+                                   state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr, part, (int*)nullptr, (int*)nullptr, 0);
+            else
+                hipLaunchKernelGGL((time_lstm_h2w8_kernel<true, false>), grid8, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
+                                   state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr);
+            return;
+        }
         if (time_lstm_fuses_fc() && fc16 && fcb && part)
             hipLaunchKernelGGL((time_lstm_h2w_kernel<true, false, true>), grid, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
                                state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr, part, ovl ? ovl->resident : (int*)nullptr,
