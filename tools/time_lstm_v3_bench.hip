@@ -135,6 +135,24 @@ static int run(int R, int T, int K, bool with_state, int reps)
             printf("     wave  8 (helper 0): per group: staging + waits %.0f ns, input half %.0f ns\n", hd[8 * 4] * 10.0 / G, hd[8 * 4 + 2] * 10.0 / G);
             printf("     wave 12 (helper 1): per group: waits %.0f ns, input half %.0f ns, fc %.0f ns\n", hd[12 * 4] * 10.0 / G, hd[12 * 4 + 2] * 10.0 / G, hd[12 * 4 + 1] * 10.0 / G);
         }
+    if (reps > 2)            // phase stamps of the eight-sequence kernel
+        for (int fz = 0; fz < 2; ++fz) {
+            const dim3 grid8((N + 7) / 8);
+            if (fz) hipLaunchKernelGGL((time_lstm_h2w8_kernel<true, true>), grid8, block16, 0, 0, z, h_fus, (const uint4*)w, b, (const uint4*)wfc, bfc, sin_, so_fus, R, T, K, (int*)nullptr, dbg);
+            else hipLaunchKernelGGL((time_lstm_h2w8_kernel<false, true>), grid8, block16, 0, 0, z, h_new, (const uint4*)w, b, (const uint4*)nullptr, (const float*)nullptr, sin_, so_new, R, T, K, (int*)nullptr, dbg);
+            CK(hipDeviceSynchronize());
+            unsigned long long hd[4 * 16 * 4];
+            CK(hipMemcpy(hd, dbg, sizeof hd, hipMemcpyDeviceToHost));
+            printf("   stamps, EIGHT sequences, %s:\n", fz ? "fused fc" : "plain");
+            for (int wv = 0; wv < 8; wv += 4) {
+                const unsigned long long* d = &hd[wv * 4];
+                printf("     wave %2d (main %d): per step: fragments + MFMAs + cells %.0f ns, wait for h(t-1) %.0f ns, wait for the group's input half / ring %.0f ns; total %.1f us\n",
+                       wv, wv / 4, d[0] * 10.0 / T, d[2] * 10.0 / T, d[3] * 10.0 / T, (d[0] + d[2] + d[3]) / 100.0);
+            }
+            const int G2 = (T + 1) / 2;
+            printf("     wave  8 (helper 0): per group of two: staging + waits %.0f ns, input half %.0f ns\n", hd[8 * 4] * 10.0 / G2, hd[8 * 4 + 2] * 10.0 / G2);
+            printf("     wave 12 (helper 1): per group of two: waits %.0f ns, input half %.0f ns, fc %.0f ns\n", hd[12 * 4] * 10.0 / G2, hd[12 * 4 + 2] * 10.0 / G2, hd[12 * 4 + 1] * 10.0 / G2);
+        }
     const int fail = (nd != 0) + (nds != 0) + (ndf != 0) + (bad != 0) + (untouched != 0) + (nd8 != 0) + (ndf8 != 0) + (nds8 != 0) + (ndsf8 != 0);
     hipFree(z); hipFree(h_old); hipFree(h_new); hipFree(h_fus); hipFree(w); hipFree(wfc); hipFree(b); hipFree(bfc);
     hipFree(st_in); hipFree(so_old); hipFree(so_new); hipFree(so_fus); hipFree(dbg);
