@@ -537,10 +537,10 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
         const bool parts = ctx_parts(c);
         const float* zi = parts && blk ? p.Z1 : p.Z0;
         if (ctx_pair(c)) {                        // both layers in one launch (A/B: BSRNN_BAND_PAIR=0)
-            OvlConsumer oc = {nullptr, 0, 0, nullptr, 0};
+            OvlConsumer oc = {nullptr, 0, 0, nullptr, 0, 2};
             const bool cons = p.ovl && blk && (p.ovl_mode & 1);
             if (cons)                             // beside the first time-axis launch: tiles in the order their frames leave it
-                oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT, p.ovl->band_order, p.ovl_base};
+                oc = OvlConsumer{c->d_ovl + OVL_HEAD, p.T, c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT, p.ovl->band_order, p.ovl_base, time_lstm_seqs(p.C * K) == 8 ? 3 : 2};
             launch_band_pair(zi, p.HB0, p.HB1, c->bandW16[blk][0], c->bandB[blk][0], c->bandW16[blk][1], c->bandB[blk][1], M, K, c->d_range, s,
                              parts ? c->bandFc16[blk] : nullptr, parts ? c->bandFcB[blk] : nullptr, p.band_flags, cons ? &oc : nullptr, nullptr, 0,
                              p.ovl ? p.band_done[blk] : nullptr);
@@ -600,7 +600,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
                 g.tasks = p.ovl->mask_tasks; g.n_tasks = p.ovl->n_mask;
                 g.ovl_prog = c->d_ovl + c->ovl_stride + OVL_HEAD; g.ovl_T = p.T; g.ovl_K = K;
                 g.ovl_spin = c->overlap_sabotage ? 200000 : OVL_SPIN_LIMIT;
-                g.ovl_base = p.ovl_base;
+                g.ovl_base = p.ovl_base; g.ovl_wg_shift = time_lstm_seqs(p.C * K) == 8 ? 3 : 2;
             }
             launch_mlp_chain(g, CHAIN_MASK, s);
             break;
@@ -627,7 +627,7 @@ void run_stage(bsrnn_ctx* c, const Part& p, int stage)
 static bool overlap_wanted(const bsrnn_ctx* c, int C, int T)
 {
     if (!c->overlap_env || c->overlap_off || !ctx_parts(c) || !c->fused || force_f32() || gemm_mode() == GEMM_F32) return false;
-    const int nwg = (C * c->K + 3) / 4;
+    const int S = time_lstm_seqs(C * c->K), nwg = (C * c->K + S - 1) / S;      // workgroups of the time-axis launch
     return !band_block_is_small(C * T, c->K) && nwg >= 32 && nwg <= 224 && T >= 32 && T < (4 << OVL_EPOCH_SHIFT) - 8 && C * T > GEMV_MAX_FRAME_ROWS;
 }
 static void free_ovl_tables(bsrnn_ctx* c)
@@ -658,7 +658,7 @@ int ensure_ovl(bsrnn_ctx* c, int C, int T)
         }
         if (c->ovl_sig[0]) c->ovl_resident_total[0] = c->ovl_resident_total[1] = 0;
     }
-    const int M = C * T, K = c->K, nwg = (C * K + 3) / 4;
+    const int M = C * T, K = c->K, S = time_lstm_seqs(C * K), nwg = (C * K + S - 1) / S;
     const int stride = OVL_HEAD + ((nwg + 15) & ~15);
     if (stride > c->ovl_stride) {
         if (c->d_ovl) { c->retired.push_back(c->d_ovl); c->d_ovl = nullptr; }      // (retired like the workspace, see ensure_ws)
@@ -732,7 +732,7 @@ void run_overlapped(bsrnn_ctx* c, Part p, const bsrnn_ctx::OvlTable* tb, int fir
     const bool band = p.ovl_mode & 1, mask = p.ovl_mode & 2, serial = p.ovl_mode & 4;
     Part pb = p;
     if (!serial) pb.s = B;
-    const int nwg = (p.C * c->K + 3) / 4, limit = OVL_SPIN_LIMIT;
+    const int S = time_lstm_seqs(p.C * c->K), nwg = (p.C * c->K + S - 1) / S, limit = OVL_SPIN_LIMIT;
     // this call's epoch (upper bits of every progress word it publishes or waits for) and the gates' targets (running totals)
     if (++c->ovl_epoch >= c->ovl_epoch_period || c->ovl_resident_total[0] > (1 << 30) || c->ovl_resident_total[1] > (1 << 30)) {   // start again: nothing in flight, every word zero
         (void)hipDeviceSynchronize();

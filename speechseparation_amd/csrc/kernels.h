@@ -128,7 +128,7 @@ struct ChainLaunch {
     unsigned long long* dbg;         // measurement only (CHAIN_TRACE builds of tools/chain_bench.hip): per-wave phase stamps
     // MASK chain launched BESIDE the time-axis launch that produces its input (api.hip, overlapped dual path): every workgroup first
     // waits until the frames of its rows have left that launch (OvlConsumer below); null = the input is complete at launch
-    const int* ovl_prog; int ovl_T, ovl_K, ovl_spin, ovl_base;
+    const int* ovl_prog; int ovl_T, ovl_K, ovl_spin, ovl_base, ovl_wg_shift;
 #ifdef CHAIN_PAIR_GEOMETRY
     // the exchange buffers and the flags of the pairs (flag [pair][sender][wave] = (pair_epoch * 16 + layers handed over) << 4 | XCC id)
     float* exch; int* pflags; int pair_epoch, pair_spin;
@@ -154,16 +154,19 @@ void launch_mlp_chain(const ChainLaunch& g, int chain, hipStream_t stream);
 // call and nothing orders the consumer's stream behind the producer's except the words themselves (an overlapped call is never captured into
 // a graph - api.hip - so by-value epochs cannot go stale; every 2^18 calls the host drains the device and starts the epochs again).
 struct OvlProducer { int* resident; int* prog; int base; };                          // base = epoch << OVL_EPOCH_SHIFT
-struct OvlConsumer { const int* prog; int T; int spin_limit; const int* order; int base; };   // spin_limit: 100 MHz ticks a wait may last
+struct OvlConsumer { const int* prog; int T; int spin_limit; const int* order; int base; int wg_shift; };   // spin_limit: 100 MHz ticks a wait may last; wg_shift: log2 of the producer's sequences per workgroup
 constexpr int OVL_EPOCH_SHIFT = 12;            // groups of four steps per launch < 4096 (frames < 16 384: api.hip checks)   // order (band launch): dispatch ordinal -> tile of 16 sequences, by the time its frames are ready
 constexpr int OVL_SPIN_LIMIT = 20000000;       // 100 MHz ticks (s_memrealtime) before a wait gives up: 200 ms - a healthy wait lasts as long as a
                                                // time-axis launch (0.1 ... a few ms); under a tool that serialises kernels (rocprofv3 --pmc) the
                                                // producer never runs beside the consumer: the call falls back after this long, once per context
 void launch_ovl_gate(const int* resident, int target, int* range_flag, int spin_limit, hipStream_t stream);
+// sequences per workgroup of the time-axis launch over N sequences: 4 (time_lstm_h2w_kernel), or 8 (time_lstm_h2w8_kernel) where four would need more than one
+// round of workgroups or BSRNN_TIME_SEQ8=1 asks for it; the launcher and whoever sizes things by that launch's workgroups (api.hip: overlap) ask here
+int time_lstm_seqs(int N);
 #if defined(__HIPCC__)
 // frame rows m_first .. m_last (m = batch row * T + frame) of bands k_first .. k_last: wait until every time-axis workgroup that owns one
-// of those sequences (n = batch row * K + band, four per workgroup) has published the groups that cover the frames.  ONE lane calls this.
-__device__ __forceinline__ bool ovl_wait_rows(const int* prog, int m_first, int m_last, int T, int K, int k_first, int k_last, int limit, int base)
+// of those sequences (n = batch row * K + band, 1 << wg_shift per workgroup) has published the groups that cover the frames.  ONE lane calls this.
+__device__ __forceinline__ bool ovl_wait_rows(const int* prog, int m_first, int m_last, int T, int K, int k_first, int k_last, int limit, int base, int wg_shift)
 {
     typedef const int __attribute__((address_space(1)))* gci;
     const gci pg = (gci)prog;
@@ -172,7 +175,7 @@ __device__ __forceinline__ bool ovl_wait_rows(const int* prog, int m_first, int 
     for (int r = r_a; r <= r_b; ++r) {
         const int t_last = r < r_b ? T - 1 : m_last - r * T;
         const int need = base + (t_last >> 2) + 1;
-        for (int wg = (r * K + k_first) >> 2; wg <= (r * K + k_last) >> 2; ++wg)
+        for (int wg = (r * K + k_first) >> wg_shift; wg <= (r * K + k_last) >> wg_shift; ++wg)
             while (__hip_atomic_load(pg + wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(16);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) return false;

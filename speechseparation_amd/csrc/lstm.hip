@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void band_pair_h2_kernel(const float* __res
         // launched beside the time-axis launch that writes z (kernels.h, OvlConsumer): wait until this tile's 16 frame rows have left it
         if (threadIdx.x == 0) {
             const int m_last = tile * 16 + 15 < N ? tile * 16 + 15 : N - 1;
-            partner_ok = ovl_wait_rows(ovl.prog, tile * 16, m_last, ovl.T, L, 0, L - 1, ovl.spin_limit, ovl.base) ? 1 : 0;
+            partner_ok = ovl_wait_rows(ovl.prog, tile * 16, m_last, ovl.T, L, 0, L - 1, ovl.spin_limit, ovl.base, ovl.wg_shift) ? 1 : 0;
         }
         __syncthreads();
         if (!partner_ok) {                        // (value 5: api.hip runs the call again launch after launch and stops overlapping)
@@ -612,7 +612,7 @@ void launch_band_pair(const float* z, float* hb0, float* hb1, const void* w0pk16
                       int* zero_words, int zero_n, hipEvent_t done)
 {
     if (N <= 0 || L <= 0) return;
-    OvlConsumer ovl = {nullptr, 0, 0, nullptr, 0};
+    OvlConsumer ovl = {nullptr, 0, 0, nullptr, 0, 2};
     if (ovlp) ovl = *ovlp;
     const dim3 grid((((N + 15) / 16 + 7) / 8) * 16), block(256);
     // test hook (tests/test_gpu_edges.py): BSRNN_BAND_PAIR=mismatch makes every workgroup publish a wrong XCC id, as if its partner sat on
@@ -2227,6 +2227,13 @@ static bool parts_add_mode()
     return on;
 }
 
+int time_lstm_seqs(int N)
+{
+    static const int seq8 = [] { const char* e = getenv("BSRNN_TIME_SEQ8"); return e ? atoi(e) : -1; }();
+    static const int cus = [] { int d = 0, n = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0 ? n : 256; }();
+    if (lstm_mode() != LSTM_FP16X2 || force_f32() || !time_lstm_fuses_fc()) return 4;
+    return seq8 == 1 || (seq8 < 0 && (N + 3) / 4 > cus) ? 8 : 4;
+}
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,
                       const void* fc16, const float* fcb, const float* part, const OvlProducer* ovl)
@@ -2240,15 +2247,14 @@ void launch_time_lstm(const float* zin, float* hout, const float* wpk, const voi
     }
     dim3 grid((N + 3) / 4), block(512), block16(1024);
     if (lstm_mode() == LSTM_FP16X2 && !force_f32()) {
-        // Eight sequences per workgroup where four would need more than one round of workgroups (one per CU): the 41-band table, large batches.
-        // BSRNN_TIME_SEQ8 = 0 never / 1 always (A/B, tests); results are bit-identical either way.
-        static const int seq8 = [] { const char* e = getenv("BSRNN_TIME_SEQ8"); return e ? atoi(e) : -1; }();
-        static const int cus = [] { int d = 0, n = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0 ? n : 256; }();
-        if (time_lstm_fuses_fc() && fc16 && fcb && !ovl && (seq8 == 1 || (seq8 < 0 && (N + 3) / 4 > cus))) {
+        // Eight sequences per workgroup where four would need more than one round of workgroups (one per CU): the 41-band table, large batches;
+        // BSRNN_TIME_SEQ8 = 0 never / 1 always (A/B, tests).  Results are bit-identical either way.
+        if (time_lstm_fuses_fc() && fc16 && fcb && time_lstm_seqs(N) == 8) {
             const dim3 grid8((N + 7) / 8);
             if (part)
                 hipLaunchKernelGGL((time_lstm_h2w8_kernel<true, false, true>), grid8, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
-                                   state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr, part, (int*)nullptr, (int*)nullptr, 0);
+                                   state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr, part, ovl ? ovl->resident : (int*)nullptr,
+                                   ovl ? ovl->prog : (int*)nullptr, ovl ? ovl->base : 0);
             else
                 hipLaunchKernelGGL((time_lstm_h2w8_kernel<true, false>), grid8, block16, 0, stream, zin, hout, (const uint4*)wpk16, bias, (const uint4*)fc16, fcb,
                                    state_in, state_out, R, T, K, range_flag, (unsigned long long*)nullptr);

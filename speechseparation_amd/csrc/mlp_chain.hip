@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void mlp_chain_kernel(ChainLaunch g)
         __shared__ int ovl_ok;
         if (threadIdx.x == 0) {
             const int rows = chain_rows(*dp), m_last = row0 + rows - 1 < g.M ? row0 + rows - 1 : g.M - 1, band = dp->z_off / HID;
-            ovl_ok = ovl_wait_rows(g.ovl_prog, row0, m_last, g.ovl_T, g.ovl_K, band, band, g.ovl_spin, g.ovl_base) ? 1 : 0;
+            ovl_ok = ovl_wait_rows(g.ovl_prog, row0, m_last, g.ovl_T, g.ovl_K, band, band, g.ovl_spin, g.ovl_base, g.ovl_wg_shift) ? 1 : 0;
         }
         __syncthreads();
         if (!ovl_ok) {                            // (value 5: api.hip runs the call again launch after launch and stops overlapping)
