@@ -156,3 +156,16 @@ def test_progress_word_epochs_start_again(sd_hot, models):
         assert torch.equal(m.separate(waves[k]), refs[k]), "call %d" % i
     m.sync()
     assert m.overlap_state() == 1
+
+
+def test_a_batch_whose_time_axis_launch_takes_eight_sequences_per_workgroup_overlaps_too(models):
+    """100 rows x 12 bands = 1 200 sequences: four per workgroup would be 300 workgroups (more than one per CU), so the time-axis launches run
+    eight per workgroup (lstm.hip::time_lstm_seqs) - 150 workgroups, inside the overlap's range: the consumers then map sequences to producer
+    workgroups eight at a time (OvlConsumer::wg_shift).  Equal to the serial flow."""
+    from speechseparation_amd import weights
+    ovl, ser = models
+    w = torch.from_numpy(weights.synth_waveform(100, 48 * 1024 + 11, seed=9)).cuda()
+    ref = ser.separate(w).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(ovl.separate(w).cpu().numpy(), ref), "call %d" % i
+    assert ovl.overlap_state() == 1
