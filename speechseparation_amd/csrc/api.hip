@@ -162,7 +162,8 @@ struct bsrnn_ctx {
     hipEvent_t ev_ovl_mid = nullptr;
 
     // concurrent row blocks of one call (bsrnn_separate)
-    // BSRNN_PARTS / BSRNN_PART_LAG.  0 = automatic: two row blocks on two streams from 128 rows on (blocks of >= 64 rows), the
+    // BSRNN_PARTS / BSRNN_PART_LAG.  0 = automatic: two row blocks on two streams once the batch's time-axis launch no longer fits one round of workgroups
+    // (bsrnn_separate: from 171 rows on at K = 12; until round 4, with four sequences per workgroup only, from 128 rows on), the
     // second one stage behind the first: one block's matrix work fills the other's latency-bound time-axis LSTM (192 of 256
     // CUs, serial chain) and the ramps / tails of the fused chain launches (+8-12 % at 128 rows).  At the benchmark's 64 rows
     // two blocks of 32 gain 3 % (1.157 -> 1.119 ms per step, BSRNN_PARTS=2) but every kernel then runs beside another
@@ -1994,7 +1995,9 @@ int bsrnn_separate(bsrnn_ctx* c, const float* wave, float* wave_out, int32_t R, 
     // stage sequence concurrently on separate streams: the ramps, tails and latency-bound stages of
     // one block (e.g. the time-axis LSTM occupies 192 of 256 CUs) overlap matrix work of the other.
     // Part j starts `lag` stages behind part j-1 so that they sit in different stages.
-    int parts = c->n_parts > 0 ? c->n_parts : (R >= 128 ? 2 : 1);
+    // (automatic: one block while the time-axis launch of the whole batch is one round of workgroups - eight sequences each from 1 024 sequences on -,
+    //  two from there: 128 / 160 rows 1.75 / 2.26 -> 1.73 / 2.18 ms with one block, 192 / 256 rows 2.59 / 3.43 ms with two against 2.72 / 3.47)
+    int parts = c->n_parts > 0 ? c->n_parts : (R >= 128 && ((int64_t)R * c->K + time_lstm_seqs(R * c->K) - 1) / time_lstm_seqs(R * c->K) > device_cus() ? 2 : 1);
     if (R < 2 * parts || (int64_t)R * T < 2048) parts = 1;
     if (parts > 1 && (rc = ensure_streams(c, parts))) return rc;
     Part pt[MAX_PARTS];

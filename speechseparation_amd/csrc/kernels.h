@@ -163,6 +163,7 @@ void launch_ovl_gate(const int* resident, int target, int* range_flag, int spin_
 // sequences per workgroup of the time-axis launch over N sequences: 4 (time_lstm_h2w_kernel), or 8 (time_lstm_h2w8_kernel) where four would need more than one
 // round of workgroups or BSRNN_TIME_SEQ8=1 asks for it; the launcher and whoever sizes things by that launch's workgroups (api.hip: overlap) ask here
 int time_lstm_seqs(int N);
+int device_cus();                                  // CUs of the current device (256 on MI355X), read once
 #if defined(__HIPCC__)
 // frame rows m_first .. m_last (m = batch row * T + frame) of bands k_first .. k_last: wait until every time-axis workgroup that owns one
 // of those sequences (n = batch row * K + band, 1 << wg_shift per workgroup) has published the groups that cover the frames.  ONE lane calls this.

@@ -2227,12 +2227,16 @@ static bool parts_add_mode()
     return on;
 }
 
+int device_cus()
+{
+    static const int cus = [] { int d = 0, n = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0 ? n : 256; }();
+    return cus;
+}
 int time_lstm_seqs(int N)
 {
     static const int seq8 = [] { const char* e = getenv("BSRNN_TIME_SEQ8"); return e ? atoi(e) : -1; }();
-    static const int cus = [] { int d = 0, n = 0; return hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0 ? n : 256; }();
     if (lstm_mode() != LSTM_FP16X2 || force_f32() || !time_lstm_fuses_fc()) return 4;
-    return seq8 == 1 || (seq8 < 0 && (N + 3) / 4 > cus) ? 8 : 4;
+    return seq8 == 1 || (seq8 < 0 && (N + 3) / 4 > device_cus()) ? 8 : 4;
 }
 void launch_time_lstm(const float* zin, float* hout, const float* wpk, const void* wpk16, const float* bias,
                       const float* state_in, float* state_out, int R, int T, int K, int* range_flag, hipStream_t stream,

@@ -241,12 +241,13 @@ def test_frame_counts_around_the_kernels_chunk_sizes(sd_default, T):
     assert maxabs(torch.cat([y1, y2], dim=2).cpu().numpy(), y_off.cpu().numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("rows", [64, 130])
+@pytest.mark.parametrize("rows", [64, 130, 200])
 def test_large_batches_equal_their_row_blocks(sd_default, rows):
-    """Rows are independent (bsrnn.py:394-395).  From 128 rows on bsrnn_separate runs two row blocks concurrently on two
-    streams (the second a stage behind): a 130-row call - and a 64-row one, the benchmark's shape - must equal the same
-    rows separated block by block, bit for bit, run to run, and the oracle on a few rows.  (This check exposed the co-residency
-    hazard of the vectorised FFT kernels, csrc/fft.hip.)"""
+    """Rows are independent (bsrnn.py:394-395).  Once a batch's time-axis launch no longer fits one round of workgroups (from 171 rows on at
+    12 bands; from 128 on until round 4) bsrnn_separate runs two row blocks concurrently on two streams (the second a stage behind): a
+    200-row call - and a 130-row one (one block, time-axis launches with eight sequences per workgroup) and a 64-row one, the benchmark's
+    shape - must equal the same rows separated block by block, bit for bit, run to run, and the oracle on a few rows.  (This check exposed
+    the co-residency hazard of the vectorised FFT kernels, csrc/fft.hip.)"""
     from oracle import bsrnn_numpy as onp
     from speechseparation_amd import weights
     m = make_model(sd_default)
